@@ -1,0 +1,268 @@
+/*
+ * mcull.h — C ABI of libmcull, the MI355X (gfx950) implementation of the GPU-driven
+ * meshlet culling path of sagizilla-dev/vulkan-renderer.
+ *
+ * The reference has no FFI: the path sits behind Vulkan descriptor bindings, a
+ * 212-byte push-constant block and an indirect buffer.  Every entry point below names
+ * the reference interface it stands in for (file:line relative to the reference
+ * checkout).  All structs are byte-identical to the reference's GPU-visible structs
+ * (shaders/common.h, Engine.hpp) so that a Vulkan frontend can hand over / consume
+ * the buffers unchanged.
+ *
+ * Conventions
+ *   - every function returns MCULL_OK (0) or a negative MCULL_E_* code; nothing
+ *     throws across the boundary (the reference's VK_CHECK, utils.hpp:68-79, throws;
+ *     the C++ wrapper in mcull.hpp restores that behaviour on top of these codes);
+ *   - a context is bound to one device and one stream and is not thread-safe;
+ *   - calls are stream-ordered and asynchronous unless the name says download /
+ *     synchronize;
+ *   - matrices are column-major float[16] exactly as glm::mat4 stores them:
+ *     element (row r, column c) is m[4*c + r].
+ */
+#ifndef MCULL_H
+#define MCULL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+#define MCULL_OK 0
+#define MCULL_E_INVALID (-1)  /* bad argument                                         */
+#define MCULL_E_HIP (-2)      /* a HIP runtime call failed (see mcull_last_error)     */
+#define MCULL_E_CAPACITY (-3) /* visible list larger than the output capacity         */
+#define MCULL_E_STATE (-4)    /* a required upload / build has not happened yet       */
+#define MCULL_E_NOMEM (-5)    /* allocation failed                                    */
+
+/* ------------------------------------------------------------- layout contract   */
+
+/* shaders/common.h:1-5, Engine.hpp:18-62.  24 bytes. */
+typedef struct mcull_vertex {
+    float vx, vy, vz, vw;   /* vw is padding                                          */
+    uint8_t nx, ny, nz, nw; /* normal, (n*0.5+0.5)*255 truncated                      */
+    uint16_t tu, tv;        /* IEEE binary16 bits                                     */
+} mcull_vertex;
+
+/* shaders/common.h:26-34, Engine.hpp:72-87.  48 bytes, 16-byte aligned in GLSL. */
+typedef struct mcull_meshlet {
+    float cone[4];          /* xyz = unit cone axis, w = sin(half angle) or 1.0       */
+    float coneApex[4];      /* xyz = vertex centroid = bounding-sphere centre, w = 0  */
+    float radius;           /* bounding-sphere radius                                 */
+    uint32_t dataOffset;    /* word offset of this meshlet's block in meshletData     */
+    uint8_t triangleCount;  /* <= 124                                                 */
+    uint8_t vertexCount;    /* <= 64                                                  */
+    uint8_t padding[6];
+} mcull_meshlet;
+
+/* shaders/common.h:7-12, Engine.hpp:89-95.  212 bytes (the push-constant block). */
+typedef struct mcull_globals {
+    float view[16];
+    float proj[16];
+    float frustum[5][4];    /* world-space planes L,R,B,T,near; inside: dot+w >= 0    */
+    uint32_t meshletCount;
+} mcull_globals;
+
+/* shaders/common.h:14-16, Engine.hpp:97-99.  64 bytes. */
+typedef struct mcull_transform {
+    float model[16];
+} mcull_transform;
+
+/* VkDrawMeshTasksIndirectCommandNV as used at Engine.cpp:1482-1483, :2439, :2539. */
+typedef struct mcull_mesh_tasks_cmd {
+    uint32_t taskCount;
+    uint32_t firstTask;
+} mcull_mesh_tasks_cmd;
+
+/* Engine.hpp:102-105: VkDrawIndexedIndirectCommand (20 B) followed by the NV command.
+ * The reference binds it with offset 20 / stride 28 (Engine.cpp:2439). */
+typedef struct mcull_draw_indirect {
+    uint32_t indexCount;
+    uint32_t instanceCount;
+    uint32_t firstIndex;
+    int32_t vertexOffset;
+    uint32_t firstInstance;
+    mcull_mesh_tasks_cmd commandMeshIndirect;
+} mcull_draw_indirect;
+
+/* One entry of the compacted visible list: the union over all task workgroups of the
+ * payload {meshletIndices[i], drawID} of shaders/shader.task:28-35, :110-117. */
+typedef struct mcull_visible {
+    uint32_t drawID;
+    uint32_t meshletID;
+} mcull_visible;
+
+/* The literal task payload of one 32-wide task workgroup (shader.task:28-35) plus
+ * gl_TaskCountNV (shader.task:117); produced by mcull_emit_task_payloads. 136 bytes. */
+typedef struct mcull_task_payload {
+    uint32_t meshletIndices[32];
+    uint32_t drawID;
+    uint32_t taskCount;
+} mcull_task_payload;
+
+#define MCULL_MAX_HIZ_LEVELS 16
+#define MCULL_MAX_VIEWS 8
+
+/* where a source / destination pointer lives */
+#define MCULL_MEM_HOST 0
+#define MCULL_MEM_DEVICE 1
+
+/* which tests run (shader.task:101 runs all three) */
+#define MCULL_TEST_FRUSTUM 1u
+#define MCULL_TEST_CONE 2u
+#define MCULL_TEST_HIZ 4u
+#define MCULL_TEST_ALL 7u
+
+/* compaction strategy */
+#define MCULL_COMPACT_ORDERED 0     /* mask -> scan -> scatter; list sorted by (drawID, meshletID),
+                                       firstTask = exclusive scan in instance order               */
+#define MCULL_COMPACT_WAVE_ATOMIC 1 /* single pass, one atomic per wavefront; list order unspecified;
+                                       per-instance taskCount exact, firstTask = 0 for every draw */
+#define MCULL_COMPACT_BLOCK_ATOMIC 2 /* single pass, one atomic per workgroup batch; as above     */
+
+/* indirect-command forms written by mcull_cull / mcull_rebase_commands */
+#define MCULL_CMD_NV_MESHLETS 0 /* {taskCount = visible_i, firstTask}: one mesh workgroup per meshlet */
+#define MCULL_CMD_NV_TASKS32 1  /* {taskCount = ceil(visible_i/32), firstTask/32 rounded}: pass-through
+                                   task stage, list padded per draw to a multiple of 32 (unsupported
+                                   with atomic compaction)                                            */
+
+typedef struct mcull_cull_params {
+    uint32_t tests;          /* MCULL_TEST_* bits                                      */
+    uint32_t compaction;     /* MCULL_COMPACT_*                                        */
+    uint32_t hiz_view;       /* which pyramid slot the Hi-Z test samples               */
+    uint32_t cmd_form;       /* MCULL_CMD_*                                            */
+    uint32_t cmd_stride;     /* bytes between commands; 0 -> 8                         */
+    uint32_t cmd_offset;     /* byte offset of the command in a record; 28/20 = DrawIndirect */
+    uint32_t write_mask;     /* non-zero: keep the 1-bit-per-pair visibility mask      */
+    uint32_t reserved;
+    /* optional caller-owned device outputs (NULL -> context-owned buffers)            */
+    mcull_visible *list;     /* capacity list_capacity entries                         */
+    uint64_t list_capacity;
+    void *commands;          /* n_instances records of cmd_stride bytes                */
+} mcull_cull_params;
+
+typedef struct mcull_cull_result {
+    const mcull_visible *list;   /* device pointer                                     */
+    const void *commands;        /* device pointer, cmd_stride * n_instances bytes     */
+    const uint64_t *total;       /* device pointer to the visible count                */
+    const uint64_t *mask;        /* device pointer, one 64-bit word per 64-meshlet group, or NULL */
+    uint64_t n_groups;           /* number of 64-meshlet groups (mask words)           */
+    uint64_t n_pairs;            /* meshlet-instances tested                           */
+} mcull_cull_result;
+
+typedef struct mcull_ctx mcull_ctx;
+
+/* ------------------------------------------------------------------ lifecycle    */
+
+/* Replaces the Vulkan bring-up the path depends on (Engine.cpp:14-53: device, queues,
+ * command pools).  `stream` is a hipStream_t (NULL = the device's null stream). */
+int mcull_create(int device_ordinal, void *stream, mcull_ctx **out);
+int mcull_destroy(mcull_ctx *ctx);
+/* Last error text of this context (VK_CHECK's stderr line, utils.hpp:72-74). */
+const char *mcull_last_error(const mcull_ctx *ctx);
+/* Text for a status code; usable without a context. */
+const char *mcull_status_string(int status);
+/* vkQueueWaitIdle equivalent for the context's stream. */
+int mcull_synchronize(mcull_ctx *ctx);
+/* Library version: major*10000 + minor*100 + patch. */
+int mcull_version(void);
+
+/* ------------------------------------------------------------------ uploads      */
+
+/* createMeshletBuffer (Engine.cpp:1427-1453; binding 2, shader.task:22-24): takes the
+ * reference's 48-byte AoS records, keeps an AoS copy and splits the culling fields into
+ * two SoA float4 streams {axis.xyz, coneW} and {centre.xyz, radius}. */
+int mcull_upload_meshlets(mcull_ctx *ctx, const mcull_meshlet *meshlets, uint64_t count, int mem);
+
+/* Direct SoA upload for scenes generated on the device (no 48-byte records exist):
+ * cone_axis_w[i] = {axis.xyz, coneW}, centre_radius[i] = {centre.xyz, radius}.
+ * With mem == MCULL_MEM_DEVICE and adopt != 0 the pointers are used in place (the caller
+ * keeps them alive); otherwise they are copied.  No reference counterpart (the reference
+ * only ever uploads AoS records, Engine.cpp:1442). */
+int mcull_upload_bounds_soa(mcull_ctx *ctx, const float *cone_axis_w, const float *centre_radius,
+                            uint64_t count, int mem, int adopt);
+
+/* createVertexBuffer + createMeshletDataBuffer (Engine.cpp:1360-1426; bindings 1 and 3,
+ * shader.mesh:27-37): inputs of the bounds computation. */
+int mcull_upload_geometry(mcull_ctx *ctx, const mcull_vertex *vertices, uint64_t vertex_count,
+                          const uint32_t *meshlet_data, uint64_t word_count, int mem);
+
+/* buildMeshletCon (Engine.cpp:472-547) for every uploaded meshlet, on the GPU: rewrites
+ * cone, coneApex and radius of the context's AoS records and refreshes the SoA streams. */
+int mcull_compute_bounds(mcull_ctx *ctx);
+
+/* Reads the context's AoS records back (after mcull_compute_bounds). Synchronous. */
+int mcull_download_meshlets(mcull_ctx *ctx, mcull_meshlet *out, uint64_t count);
+
+/* createTransformBuffers + the memcpy of updateTransforms (Engine.cpp:1454-1465, :2378;
+ * binding 4, shader.task:18-20). */
+int mcull_upload_transforms(mcull_ctx *ctx, const mcull_transform *transforms, uint64_t count, int mem);
+
+/* Per-instance meshlet range [offset, offset+count) into the uploaded meshlet array.
+ * NULL pointers restore the reference behaviour: every instance draws
+ * [0, globals.meshletCount) (shader.task:85).  Host pointers.  Extension needed for
+ * scenes that mix meshes; no reference counterpart. */
+int mcull_set_instance_ranges(mcull_ctx *ctx, const uint32_t *meshlet_offset,
+                              const uint32_t *meshlet_count, uint64_t n_instances);
+
+/* ------------------------------------------------------------------ Hi-Z pyramid */
+
+/* hiZMipLevels (Engine.cpp:1651): floor(log2(max(w,h))) + 1. */
+uint32_t mcull_hiz_level_count(uint32_t width, uint32_t height);
+/* Level extents max(1, w>>i) x max(1, h>>i) (Engine.cpp:1845-1846) and float offsets of
+ * each level inside the flat pyramid buffer. Returns the total float count. */
+uint64_t mcull_hiz_layout(uint32_t width, uint32_t height, uint32_t *levels,
+                          uint32_t level_width[MCULL_MAX_HIZ_LEVELS],
+                          uint32_t level_height[MCULL_MAX_HIZ_LEVELS],
+                          uint64_t level_offset[MCULL_MAX_HIZ_LEVELS]);
+
+/* createHiZPyramid + buildHiZPyramid + shaders/shader.comp (Engine.cpp:1658-1685,
+ * :1834-1866; shader.comp:12-31): level 0 = copy of depth, level i = 2x2 min of level
+ * i-1, all levels in one launch.  `view` selects one of MCULL_MAX_VIEWS pyramid slots. */
+int mcull_hiz_build(mcull_ctx *ctx, uint32_t view, const float *depth, uint32_t width,
+                    uint32_t height, int mem);
+/* Device pointer of a slot's flat pyramid (layout as mcull_hiz_layout). */
+int mcull_hiz_pyramid(mcull_ctx *ctx, uint32_t view, const float **device_ptr, uint64_t *float_count);
+/* Copies one level to the host. Synchronous. */
+int mcull_hiz_download_level(mcull_ctx *ctx, uint32_t view, uint32_t level, float *out);
+
+/* ------------------------------------------------------------------ cull+compact */
+
+/* vkCmdPushConstants(Globals) + vkCmdDrawMeshTasksIndirectNV (Engine.cpp:2535-2539) and
+ * the task shader it launches (shaders/shader.task:37-119): tests every
+ * (instance, meshlet) pair, compacts the survivors into one global visible list and
+ * writes one indirect command per instance (createIndirectBuffer, Engine.cpp:1466-1484,
+ * made dynamic).  `params` may be NULL (all tests, ordered compaction, 8-byte commands).
+ * Returns MCULL_E_CAPACITY only from the download/count calls, never asynchronously. */
+int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
+               mcull_cull_result *result);
+
+/* Multi-GPU: re-emits the indirect commands of the last mcull_cull with
+ * firstTask += sum(totals[0..rank)), where `totals` is the device array produced by an
+ * all-gather of every rank's *result.total.  No reference counterpart (single GPU). */
+int mcull_rebase_commands(mcull_ctx *ctx, const uint64_t *device_totals, uint32_t rank);
+
+/* The literal per-32 task payloads of shader.task:28-35,:103-118 for the last ordered
+ * mcull_cull: one record per (instance, group of 32 meshlets).  `out` is a device buffer
+ * of at least mcull_task_payload_count() records. */
+uint64_t mcull_task_payload_count(const mcull_ctx *ctx);
+int mcull_emit_task_payloads(mcull_ctx *ctx, mcull_task_payload *out);
+
+/* Synchronous read-backs of the last mcull_cull. */
+int mcull_download_count(mcull_ctx *ctx, uint64_t *total);
+/* MCULL_E_CAPACITY (and *total = required entries) when the list did not fit. */
+int mcull_download_list(mcull_ctx *ctx, mcull_visible *out, uint64_t capacity, uint64_t *total);
+int mcull_download_commands(mcull_ctx *ctx, void *out, uint64_t bytes);
+int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
+
+/* Device time of the kernels of the last mcull_cull / mcull_hiz_build /
+ * mcull_compute_bounds in milliseconds (HIP events on the context's stream;
+ * the reference's timestamp queries, Engine.cpp:2393-2394, :2548). Synchronous. */
+int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCULL_H */

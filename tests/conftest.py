@@ -1,0 +1,71 @@
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (runs the HIP kernels through the C ABI)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU oracle (test infrastructure)."""
+    import oracle
+
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def mc():
+    """The product binding (ctypes over libmcull.so)."""
+    return importlib.import_module("vulkan-renderer_amd")
+
+
+@pytest.fixture(scope="session")
+def H():
+    return importlib.import_module("vulkan-renderer_amd.host")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def load_scene(name, oracle):
+    z = np.load(os.path.join(GOLDEN, name + "_scene.npz"))
+    return dict(vertices=z["vertices"].view(oracle.VERTEX), meshlet_data=z["meshlet_data"],
+                meshlets=z["meshlets"].view(oracle.MESHLET))
+
+
+@pytest.fixture(scope="session")
+def kitten(O):
+    return load_scene("kitten", O)
+
+
+@pytest.fixture(scope="session")
+def bunny(O):
+    return load_scene("bunny", O)
+
+
+@pytest.fixture(scope="session")
+def config1(O):
+    z = np.load(os.path.join(GOLDEN, "config1_inputs.npz"))
+    return dict(globals=z["globals"].view(O.GLOBALS), transforms=z["transforms"].view(O.TRANSFORM))
+
+
+@pytest.fixture(scope="session")
+def ctx(mc):
+    c = mc.Context(0)
+    yield c
+    c.close()

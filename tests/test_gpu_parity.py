@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bars: visibility masks, compacted lists (after sorting where the mode leaves order open), indirect
+commands and Hi-Z pyramids bit-exact; bounds bit-exact (the contract allows 1e-5 relative).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def sorted_list(lst):
+    a = np.asarray(lst).view("<u4").reshape(-1, 2).astype(np.uint64)
+    return np.sort((a[:, 0] << np.uint64(32)) | a[:, 1])
+
+
+def check_against_oracle(mc, ctx, r_ref, n_inst, compaction, stride=8, offset=0):
+    total = ctx.download_count()
+    assert total == r_ref.total
+    lst = ctx.download_list()
+    if compaction == mc.COMPACT_ORDERED:
+        assert lst.tobytes() == r_ref.list.tobytes(), "ordered list must equal the oracle's sorted list"
+    else:
+        assert np.array_equal(sorted_list(lst), sorted_list(r_ref.list))
+    raw = ctx.download_commands(n_inst, stride).reshape(n_inst, stride)
+    cmds = raw[:, offset:offset + 8].copy().view(mc.CMD).reshape(-1)
+    assert np.array_equal(cmds["taskCount"], r_ref.commands["taskCount"])
+    if compaction == mc.COMPACT_ORDERED:
+        assert np.array_equal(cmds["firstTask"], r_ref.commands["firstTask"])
+    return cmds
+
+
+@pytest.mark.parametrize("tests", [7, 3, 1, 2, 4, 0])
+@pytest.mark.parametrize("compaction", [0, 1, 2])
+def test_config1_kitten(mc, O, ctx, kitten, config1, H, tests, compaction):
+    """Config 1: kitten x 1000 instances at 800x600 with every test combination and compaction mode."""
+    g, t = config1["globals"], config1["transforms"]
+    depth = H.synthetic_depth(800, 600, n_discs=24, seed=5)
+    pyr = O.hiz_build(depth)
+    view = O.View(g, pyr, 800, 600)
+    ref = O.cull_scene(view, t, kitten["meshlets"], tests=tests)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    ctx.hiz_build(depth, view=0)
+    ctx.cull(g, tests=tests, compaction=compaction, write_mask=True)
+    mask = ctx.download_mask()
+    assert np.array_equal(mask, ref.mask), "visibility mask must be bit-exact"
+    check_against_oracle(mc, ctx, ref, len(t), compaction)
+
+
+def test_config1_golden_hashes(mc, O, ctx, kitten, config1, manifest):
+    """The committed golden hashes of config 1 (cleared depth) reproduced by the GPU."""
+    g, t = config1["globals"], config1["transforms"]
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    ctx.hiz_build(np.zeros((600, 800), dtype="<f4"), view=0)
+    for label, tests in (("all", 7), ("frustum_cone", 3), ("frustum", 1), ("cone", 2)):
+        want = manifest["config1"]["results"][label]
+        ctx.cull(g, tests=tests)
+        assert ctx.download_count() == want["total"]
+        assert "%016x" % O.fnv1a64(ctx.download_list()) == want["fnv_list"]
+        assert "%016x" % O.fnv1a64(ctx.download_mask()) == want["fnv_mask"]
+        assert "%016x" % O.fnv1a64(ctx.download_commands(len(t))) == want["fnv_commands"]
+
+
+def test_draw_indirect_layout(mc, O, ctx, kitten, config1):
+    """Commands written at the reference's DrawIndirect stride/offset (28/20, Engine.cpp:2439)."""
+    g, t = config1["globals"], config1["transforms"]
+    view = O.View(g)
+    ref = O.cull_scene(view, t, kitten["meshlets"], tests=3)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    ctx.cull(g, tests=3, cmd_stride=28, cmd_offset=20)
+    raw = ctx.download_commands(len(t), 28).reshape(len(t), 28)
+    assert not raw[:, :20].any(), "bytes outside the NV command are left untouched"
+    check_against_oracle(mc, ctx, ref, len(t), 0, 28, 20)
+
+
+def test_task_payloads(mc, O, ctx, kitten, config1):
+    """The literal per-32 task payloads of shader.task:28-35,:103-118."""
+    g, t = config1["globals"], config1["transforms"][:100]
+    view = O.View(g)
+    ref = O.task_payloads(view, t, kitten["meshlets"], tests=3)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    ctx.cull(g, tests=3)
+    got = ctx.task_payloads()
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_mixed_meshes_and_ragged_ranges(mc, O, ctx, kitten, bunny, H):
+    """Config 2 shape: instances drawing different meshes through per-instance ranges, including an
+    empty instance, a 1-meshlet instance and ranges that are not multiples of 64."""
+    meshlets = np.concatenate([kitten["meshlets"], bunny["meshlets"]])
+    nk, nb = len(kitten["meshlets"]), len(bunny["meshlets"])
+    n = 600
+    t = H.update_transforms(n)
+    off = np.zeros(n, dtype="<u4"); cnt = np.zeros(n, dtype="<u4")
+    for i in range(n):
+        k = i % 5
+        if k == 0: off[i], cnt[i] = 0, nk
+        elif k == 1: off[i], cnt[i] = nk, nb
+        elif k == 2: off[i], cnt[i] = 17, 64
+        elif k == 3: off[i], cnt[i] = nk + 5, 1
+        else: off[i], cnt[i] = 0, 0
+    g = H.create_globals(meshlet_count=0)
+    view = O.View(g)
+    ctx.upload_meshlets(meshlets)
+    ctx.upload_transforms(t)
+    ctx.set_instance_ranges(off, cnt)
+    for compaction in (0, 1, 2):
+        for tests in (3, 1):
+            ref = O.cull_scene(view, t, meshlets, ranges=(off, cnt), tests=tests)
+            ctx.cull(g, tests=tests, compaction=compaction, write_mask=True)
+            assert np.array_equal(ctx.download_mask(), ref.mask)
+            check_against_oracle(mc, ctx, ref, n, compaction)
+    ctx.set_instance_ranges(None, None)
+
+
+def test_synthetic_scene_soa(mc, O, ctx, H):
+    """Config 4 shape at a size the oracle finishes in seconds: unique meshlets per instance (SoA
+    upload), Hi-Z on, unflipped projection so that mip levels above 0 are exercised."""
+    n_inst, per = 4096, 128
+    cone, sphere = H.synthetic_bounds(n_inst * per, seed=1)
+    t = H.synthetic_transforms(n_inst, extent=50.0, seed=2)
+    off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+    cnt = np.full(n_inst, per, dtype="<u4")
+    w, h = 1024, 512
+    depth = H.synthetic_depth(w, h, n_discs=40, seed=3)
+    for flip in (True, False):
+        g = H.create_globals(eye=(150.0, 140.0, 130.0), fov_deg=50.0, width=w, height=h, flip_y=flip)
+        pyr = O.hiz_build(depth)
+        view = O.View(g, pyr, w, h)
+        ref = O.cull_scene(view, t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=7, threads=8)
+        ctx.upload_bounds_soa(cone, sphere)
+        ctx.upload_transforms(t)
+        ctx.set_instance_ranges(off, cnt)
+        ctx.hiz_build(depth, view=1)
+        for compaction in (0, 1, 2):
+            ctx.cull(g, tests=7, hiz_view=1, compaction=compaction, write_mask=True)
+            assert np.array_equal(ctx.download_mask(), ref.mask)
+            check_against_oracle(mc, ctx, ref, n_inst, compaction)
+        assert 0 < ref.total < ref.n_pairs
+    ctx.set_instance_ranges(None, None)
+
+
+@pytest.mark.parametrize("shape", [(600, 800), (3, 5), (1, 1), (64, 64), (65, 127), (768, 1024), (1080, 1920),
+                                   (37, 4000), (2160, 3840), (1, 300), (2, 2), (4, 4), (129, 130)])
+def test_hiz_pyramid_bit_exact(mc, O, ctx, shape):
+    """Every texel of every level, bit for bit, including odd sizes, collapse cases and NaN/-0."""
+    h, w = shape
+    rs = np.random.RandomState(h * 7919 + w)
+    depth = rs.uniform(0, 1, (h, w)).astype("<f4")
+    if h * w > 16:
+        depth.flat[rs.randint(0, h * w, 8)] = [np.nan, -0.0, 0.0, np.inf, -np.inf, 1e-40, np.nan, 0.5]
+    ref = O.hiz_levels(O.hiz_build(depth), w, h)
+    ctx.hiz_build(depth, view=2)
+    got = ctx.hiz_download(view=2)
+    assert len(got) == len(ref) == mc.hiz_layout(w, h)[0]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert a.shape == b.shape
+        assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "level %d differs" % k
+
+
+def test_hiz_large_closed_form(mc, ctx):
+    """8192^2 (config 5's size): level k equals the block minimum of level 0 (size-independent property)."""
+    import torch
+
+    w = h = 8192
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    d = torch.rand((h, w), device="cuda", dtype=torch.float32, generator=gen)
+    ctx.hiz_build(d.data_ptr(), view=3, width=w, height=h, mem=mc.MEM_DEVICE)
+    ctx.synchronize()
+    ptr, n = ctx.hiz_pyramid_ptr(3)
+    levels, lw, lh, off, total = mc.hiz_layout(w, h)
+    assert n == total and levels == 14
+    pyr = torch.empty(total, device="cuda", dtype=torch.float32)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(pyr.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(total * 4), 3) == 0
+    cur = d
+    for k in range(levels):
+        lvl = pyr[off[k]: off[k] + lw[k] * lh[k]].view(lh[k], lw[k])
+        assert torch.equal(lvl, cur), "level %d" % k
+        if k + 1 < levels:
+            cur = -torch.nn.functional.max_pool2d(-cur[None, None], 2)[0, 0]
+
+
+def test_bounds_bit_exact(mc, O, ctx, kitten, bunny):
+    """mcull_compute_bounds vs buildMeshletCon on kitten and bunny: cone, apex, radius."""
+    for scene in (kitten, bunny):
+        blank = scene["meshlets"].copy()
+        blank["cone"] = 0; blank["coneApex"] = 0; blank["radius"] = 0
+        ctx.upload_meshlets(blank)
+        ctx.upload_geometry(scene["vertices"], scene["meshlet_data"])
+        ctx.compute_bounds()
+        got = ctx.download_meshlets(len(blank))
+        ref = scene["meshlets"]
+        for f in ("cone", "coneApex", "radius"):
+            a, b = got[f], ref[f]
+            rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+            assert np.all((rel <= 1e-5) | (a == b)), f
+            assert a.tobytes() == b.tobytes(), "%s not bit-exact" % f
+        assert got.tobytes() == ref.tobytes()
+
+
+def test_errors(mc, ctx, kitten, config1):
+    g, t = config1["globals"], config1["transforms"]
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    bad = g.copy(); bad["meshletCount"] = 10 ** 6
+    with pytest.raises(mc.McullError) as e:
+        ctx.cull(bad)
+    assert e.value.status == mc.E_INVALID
+    with pytest.raises(mc.McullError) as e:
+        ctx.cull(g, tests=7, hiz_view=7)
+    assert e.value.status == mc.E_STATE
+    # capacity overflow is detected, never written past
+    ctx.cull(g, tests=2, list_capacity=1000)
+    with pytest.raises(mc.McullError) as e:
+        ctx.download_list()
+    assert e.value.status == mc.E_CAPACITY
+    assert ctx.download_count() > 1000

@@ -1,0 +1,288 @@
+"""Host-side binding of libmcull (the MI355X culling path) over its C ABI (include/mcull.h).
+
+The package holds only what the path needs: csrc/ (HIP kernels + the C ABI) and this thin ctypes
+mirror of the ABI.  There is no CPU fallback: importing works without a GPU (so the ABI can be
+inspected), but every compute call goes to the gfx950 kernels and raises McullError otherwise.
+A missing libmcull.so raises at import.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcull.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libmcull.so is missing (%s): build it with `make -C %s/csrc` (hipcc, gfx950)" % (LIB_PATH, _HERE)
+    )
+# PyTorch ships its own copy of the HIP runtime (same soname as the system one).  When torch is
+# going to share this process (device memory, streams, torch.distributed), it must be loaded first
+# so that libmcull.so binds to that same runtime instead of bringing in a second one.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a pure C-ABI consumer without torch uses the system runtime
+    torch = None
+lib = C.CDLL(LIB_PATH)
+
+# ---- layout contract (numpy views of the structs in include/mcull.h)
+VERTEX = np.dtype([("pos", "<f4", 4), ("n", "u1", 4), ("uv", "<u2", 2)])
+MESHLET = np.dtype(
+    [("cone", "<f4", 4), ("coneApex", "<f4", 4), ("radius", "<f4"), ("dataOffset", "<u4"),
+     ("triangleCount", "u1"), ("vertexCount", "u1"), ("padding", "u1", 6)]
+)
+GLOBALS = np.dtype([("view", "<f4", 16), ("proj", "<f4", 16), ("frustum", "<f4", (5, 4)), ("meshletCount", "<u4")])
+TRANSFORM = np.dtype([("model", "<f4", 16)])
+CMD = np.dtype([("taskCount", "<u4"), ("firstTask", "<u4")])
+DRAW_INDIRECT = np.dtype(
+    [("indexCount", "<u4"), ("instanceCount", "<u4"), ("firstIndex", "<u4"), ("vertexOffset", "<i4"),
+     ("firstInstance", "<u4"), ("commandMeshIndirect", CMD)]
+)
+VISIBLE = np.dtype([("drawID", "<u4"), ("meshletID", "<u4")])
+TASK_PAYLOAD = np.dtype([("meshletIndices", "<u4", 32), ("drawID", "<u4"), ("taskCount", "<u4")])
+
+OK, E_INVALID, E_HIP, E_CAPACITY, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5
+MEM_HOST, MEM_DEVICE = 0, 1
+TEST_FRUSTUM, TEST_CONE, TEST_HIZ, TEST_ALL = 1, 2, 4, 7
+COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
+CMD_NV_MESHLETS, CMD_NV_TASKS32 = 0, 1
+MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
+
+# every symbol include/mcull.h declares
+ABI_SYMBOLS = [
+    "mcull_create", "mcull_destroy", "mcull_last_error", "mcull_status_string", "mcull_synchronize", "mcull_version",
+    "mcull_upload_meshlets", "mcull_upload_bounds_soa", "mcull_upload_geometry", "mcull_compute_bounds",
+    "mcull_download_meshlets", "mcull_upload_transforms", "mcull_set_instance_ranges", "mcull_hiz_level_count",
+    "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
+    "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
+    "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_last_kernel_ms",
+]
+
+
+class CullParams(C.Structure):
+    _fields_ = [("tests", C.c_uint32), ("compaction", C.c_uint32), ("hiz_view", C.c_uint32), ("cmd_form", C.c_uint32),
+                ("cmd_stride", C.c_uint32), ("cmd_offset", C.c_uint32), ("write_mask", C.c_uint32),
+                ("reserved", C.c_uint32), ("list", C.c_void_p), ("list_capacity", C.c_uint64),
+                ("commands", C.c_void_p)]
+
+
+class CullResult(C.Structure):
+    _fields_ = [("list", C.c_void_p), ("commands", C.c_void_p), ("total", C.c_void_p), ("mask", C.c_void_p),
+                ("n_groups", C.c_uint64), ("n_pairs", C.c_uint64)]
+
+
+def _sig(name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype, f.argtypes = restype, argtypes
+
+
+_P, _U64, _U32, _I = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+_sig("mcull_create", _I, [_I, _P, C.POINTER(_P)])
+_sig("mcull_destroy", _I, [_P])
+_sig("mcull_last_error", C.c_char_p, [_P])
+_sig("mcull_status_string", C.c_char_p, [_I])
+_sig("mcull_synchronize", _I, [_P])
+_sig("mcull_version", _I, [])
+_sig("mcull_upload_meshlets", _I, [_P, _P, _U64, _I])
+_sig("mcull_upload_bounds_soa", _I, [_P, _P, _P, _U64, _I, _I])
+_sig("mcull_upload_geometry", _I, [_P, _P, _U64, _P, _U64, _I])
+_sig("mcull_compute_bounds", _I, [_P])
+_sig("mcull_download_meshlets", _I, [_P, _P, _U64])
+_sig("mcull_upload_transforms", _I, [_P, _P, _U64, _I])
+_sig("mcull_set_instance_ranges", _I, [_P, _P, _P, _U64])
+_sig("mcull_hiz_level_count", _U32, [_U32, _U32])
+_sig("mcull_hiz_layout", _U64, [_U32, _U32, C.POINTER(_U32), _P, _P, _P])
+_sig("mcull_hiz_build", _I, [_P, _U32, _P, _U32, _U32, _I])
+_sig("mcull_hiz_pyramid", _I, [_P, _U32, C.POINTER(_P), C.POINTER(_U64)])
+_sig("mcull_hiz_download_level", _I, [_P, _U32, _U32, _P])
+_sig("mcull_cull", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
+_sig("mcull_rebase_commands", _I, [_P, _P, _U32])
+_sig("mcull_task_payload_count", _U64, [_P])
+_sig("mcull_emit_task_payloads", _I, [_P, _P])
+_sig("mcull_download_count", _I, [_P, C.POINTER(_U64)])
+_sig("mcull_download_list", _I, [_P, _P, _U64, C.POINTER(_U64)])
+_sig("mcull_download_commands", _I, [_P, _P, _U64])
+_sig("mcull_download_mask", _I, [_P, _P, _U64])
+_sig("mcull_last_kernel_ms", _I, [_P, C.POINTER(C.c_float)])
+
+
+class McullError(RuntimeError):
+    def __init__(self, status, text):
+        RuntimeError.__init__(self, "%s: %s" % (lib.mcull_status_string(status).decode(), text))
+        self.status = status
+
+
+def version():
+    return int(lib.mcull_version())
+
+
+def hiz_layout(width, height):
+    """(levels, widths, heights, float offsets, total floats) of the flat pyramid."""
+    n = _U32()
+    lw, lh, off = (_U32 * 16)(), (_U32 * 16)(), (_U64 * 16)()
+    total = lib.mcull_hiz_layout(width, height, C.byref(n), lw, lh, off)
+    k = n.value
+    return k, list(lw)[:k], list(lh)[:k], list(off)[:k], int(total)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One device + one stream (mcull_ctx).  Pointer arguments are numpy arrays (host) or
+    integer device addresses with mem=MEM_DEVICE."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _P()
+        rc = lib.mcull_create(device, stream, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise McullError(rc, "mcull_create(device=%d) failed; an MI355X (gfx950) device is required" % device)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mcull_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise McullError(rc, lib.mcull_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._chk(lib.mcull_synchronize(self._h))
+
+    # ---- uploads
+    def upload_meshlets(self, meshlets, count=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            meshlets = np.ascontiguousarray(meshlets, dtype=MESHLET)
+            self._chk(lib.mcull_upload_meshlets(self._h, _np_ptr(meshlets), len(meshlets), MEM_HOST))
+        else:
+            self._chk(lib.mcull_upload_meshlets(self._h, meshlets, count, MEM_DEVICE))
+
+    def upload_bounds_soa(self, cone_axis_w, centre_radius, count=None, mem=MEM_HOST, adopt=False):
+        if mem == MEM_HOST:
+            a = np.ascontiguousarray(cone_axis_w, dtype="<f4").reshape(-1, 4)
+            b = np.ascontiguousarray(centre_radius, dtype="<f4").reshape(-1, 4)
+            assert len(a) == len(b)
+            self._chk(lib.mcull_upload_bounds_soa(self._h, _np_ptr(a), _np_ptr(b), len(a), MEM_HOST, 0))
+        else:
+            self._chk(lib.mcull_upload_bounds_soa(self._h, cone_axis_w, centre_radius, count, MEM_DEVICE, int(adopt)))
+
+    def upload_geometry(self, vertices, meshlet_data):
+        v = np.ascontiguousarray(vertices, dtype=VERTEX)
+        d = np.ascontiguousarray(meshlet_data, dtype="<u4")
+        self._chk(lib.mcull_upload_geometry(self._h, _np_ptr(v), len(v), _np_ptr(d), len(d), MEM_HOST))
+
+    def compute_bounds(self):
+        self._chk(lib.mcull_compute_bounds(self._h))
+
+    def download_meshlets(self, count):
+        out = np.zeros(count, dtype=MESHLET)
+        self._chk(lib.mcull_download_meshlets(self._h, _np_ptr(out), count))
+        return out
+
+    def upload_transforms(self, transforms, count=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            t = np.ascontiguousarray(transforms, dtype=TRANSFORM)
+            self._chk(lib.mcull_upload_transforms(self._h, _np_ptr(t), len(t), MEM_HOST))
+        else:
+            self._chk(lib.mcull_upload_transforms(self._h, transforms, count, MEM_DEVICE))
+
+    def set_instance_ranges(self, offsets, counts):
+        if offsets is None:
+            self._chk(lib.mcull_set_instance_ranges(self._h, None, None, 0))
+            return
+        o = np.ascontiguousarray(offsets, dtype="<u4")
+        n = np.ascontiguousarray(counts, dtype="<u4")
+        assert len(o) == len(n)
+        self._chk(lib.mcull_set_instance_ranges(self._h, _np_ptr(o), _np_ptr(n), len(o)))
+
+    # ---- Hi-Z
+    def hiz_build(self, depth, view=0, width=None, height=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            d = np.ascontiguousarray(depth, dtype="<f4")
+            height, width = d.shape
+            self._chk(lib.mcull_hiz_build(self._h, view, _np_ptr(d), width, height, MEM_HOST))
+        else:
+            self._chk(lib.mcull_hiz_build(self._h, view, depth, width, height, MEM_DEVICE))
+        self._hiz_dims = getattr(self, "_hiz_dims", {})
+        self._hiz_dims[view] = (width, height)
+
+    def hiz_pyramid_ptr(self, view=0):
+        p, n = _P(), _U64()
+        self._chk(lib.mcull_hiz_pyramid(self._h, view, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def hiz_download(self, view=0):
+        """All levels as a list of (h, w) float32 arrays."""
+        w, h = self._hiz_dims[view]
+        n, lw, lh, _, _ = hiz_layout(w, h)
+        out = []
+        for k in range(n):
+            a = np.zeros((lh[k], lw[k]), dtype="<f4")
+            self._chk(lib.mcull_hiz_download_level(self._h, view, k, _np_ptr(a)))
+            out.append(a)
+        return out
+
+    # ---- cull + compact
+    def cull(self, globals_, tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
+             cmd_stride=8, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None):
+        g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
+        p = CullParams(tests, compaction, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)), 0,
+                       list_ptr, list_capacity, commands_ptr)
+        r = CullResult()
+        self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
+        self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
+        return r
+
+    def rebase_commands(self, device_totals_ptr, rank):
+        self._chk(lib.mcull_rebase_commands(self._h, device_totals_ptr, rank))
+
+    def download_count(self):
+        n = _U64()
+        self._chk(lib.mcull_download_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def download_list(self, capacity=None):
+        n = self.download_count() if capacity is None else capacity
+        out = np.zeros(max(n, 1), dtype=VISIBLE)
+        tot = _U64()
+        self._chk(lib.mcull_download_list(self._h, _np_ptr(out), n, C.byref(tot)))
+        return out[: int(tot.value)]
+
+    def download_commands(self, n_instances, stride=8):
+        raw = np.zeros(n_instances * stride, dtype="u1")
+        self._chk(lib.mcull_download_commands(self._h, _np_ptr(raw), raw.nbytes))
+        return raw
+
+    def download_mask(self):
+        words = self._last[0]
+        out = np.zeros(max(words, 1), dtype="<u8")
+        self._chk(lib.mcull_download_mask(self._h, _np_ptr(out), words))
+        return out[:words]
+
+    def task_payloads(self):
+        """Literal per-32 task payloads of the last ordered cull (device buffer from torch)."""
+        import torch
+
+        n = int(lib.mcull_task_payload_count(self._h))
+        buf = torch.empty(max(n, 1) * TASK_PAYLOAD.itemsize, dtype=torch.uint8, device="cuda:%d" % self.device)
+        self._chk(lib.mcull_emit_task_payloads(self._h, buf.data_ptr()))
+        self.synchronize()
+        return np.frombuffer(buf.cpu().numpy().tobytes(), dtype=TASK_PAYLOAD)[:n]
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(lib.mcull_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,480 @@
+// Cull + compact kernels for gfx950 (wave64).
+//
+// Work unit: a *group* = 64 consecutive meshlets of one instance, one meshlet per lane, so the
+// instance transform is wave-uniform (scalar loads -> SGPRs) and the two SoA bounds streams are
+// read with one coalesced 16-byte load per lane each (1 KiB per wave-instruction).
+//
+// Arithmetic: this file is compiled with -ffp-contract=off and default (correctly rounded)
+// division / sqrt, and every expression below fixes its association order, so that each test
+// evaluates to the same IEEE binary32 value as the scalar CPU transcription of
+// shaders/shader.task:37-101.
+//
+// Compaction strategies:
+//   ordered      cull_mask_kernel  -> one 64-bit ballot word per group + one count per workgroup
+//                compact_kernel    -> workgroup base = sum of lower workgroups' counts, block scan,
+//                                     scatter; list sorted by (drawID, meshletID)
+//                emit_commands_kernel -> {taskCount, firstTask} per instance
+//   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
+//                workgroup step), list order unspecified.
+#include "mcull_internal.h"
+
+namespace mcull {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// clamp(ceil(log2(max(px, 1))), 0, levels-1) evaluated exactly from the float's bits
+// (shader.task:71-72).  NaN and px <= 1 give level 0.
+__device__ __forceinline__ uint32_t mip_level(float px, uint32_t levels) {
+    if (!(px > 1.0f)) return 0u;
+    uint32_t bits = __float_as_uint(px);
+    uint32_t e = (bits >> 23) & 0xffu, mant = bits & 0x7fffffu;
+    uint32_t l = (e == 0xffu) ? 0xffu : (e - 127u) + (mant ? 1u : 0u);
+    return l > levels - 1u ? levels - 1u : l;
+}
+
+// nearest + REPEAT addressing (Engine.cpp:1623-1627): floor(u*size) mod size; a scaled
+// coordinate that is not finite and below 1e9 in magnitude addresses texel 0.
+__device__ __forceinline__ uint32_t wrap_texel(float scaled_floor, uint32_t size) {
+    if (!(fabsf(scaled_floor) < 1.0e9f)) return 0u;
+    int32_t i = (int32_t)scaled_floor;
+    int32_t m = i % (int32_t)size;
+    if (m < 0) m += (int32_t)size;
+    return (uint32_t)m;
+}
+
+struct Xform {
+    float4 c0, c1, c2, c3;  // columns of the model matrix
+};
+
+// shader.task:85-101 for one pair.  `a` = {axis.xyz, coneW}, `c` = {centre.xyz, radius}.
+__device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float4 a, float4 c) {
+    // world-space centre (shader.task:91), axis (:95), radius (:99)
+    const float wx = ((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x;
+    const float wy = ((m.c0.y * c.x + m.c1.y * c.y) + m.c2.y * c.z) + m.c3.y;
+    const float wz = ((m.c0.z * c.x + m.c1.z * c.y) + m.c2.z * c.z) + m.c3.z;
+    const float r = c.w * sqrtf(dot3(m.c0.x, m.c0.y, m.c0.z, m.c0.x, m.c0.y, m.c0.z));
+
+    bool culled = false;
+    if (v.tests & MCULL_TEST_FRUSTUM) {  // frustumCull, shader.task:43-56
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const float d = (dot3(v.frustum[i][0], v.frustum[i][1], v.frustum[i][2], wx, wy, wz) + v.frustum[i][3]) + r;
+            culled |= d < 0.0f;
+        }
+    }
+    if ((v.tests & MCULL_TEST_HIZ) && !culled) {  // occlusionCull, shader.task:58-77
+        const float cx = ((v.vp[0] * wx + v.vp[4] * wy) + v.vp[8] * wz) + v.vp[12];
+        const float cy = ((v.vp[1] * wx + v.vp[5] * wy) + v.vp[9] * wz) + v.vp[13];
+        const float cz = ((v.vp[2] * wx + v.vp[6] * wy) + v.vp[10] * wz) + v.vp[14];
+        const float cw = ((v.vp[3] * wx + v.vp[7] * wy) + v.vp[11] * wz) + v.vp[15];
+        const float nx = cx / cw, ny = cy / cw, nz = cz / cw;
+        const float ndc_radius = (v.proj11 * r) / cw;
+        const float tu = nx * 0.5f + 0.5f;
+        const float tv = 1.0f - (ny * 0.5f + 0.5f);
+        const float px = (ndc_radius * 2.0f) * v.tex_max;
+        const uint32_t mip = mip_level(px, v.levels);
+        const uint32_t lw = v.level_table[mip], lh = v.level_table[16 + mip], lo = v.level_table[32 + mip];
+        const uint32_t tx = wrap_texel(floorf(tu * (float)lw), lw);
+        const uint32_t ty = wrap_texel(floorf(tv * (float)lh), lh);
+        const float d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];
+        culled = nz < d - 0.05f;
+    }
+    if ((v.tests & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
+        float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
+        float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
+        float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
+        const float ia = 1.0f / sqrtf(dot3(ax, ay, az, ax, ay, az));
+        ax *= ia; ay *= ia; az *= ia;
+        float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
+        const float iv = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+        vx *= iv; vy *= iv; vz *= iv;
+        culled = dot3(ax, ay, az, vx, vy, vz) < -a.w;
+    }
+    return !culled;
+}
+
+// Which instance / local group / meshlet range a group belongs to.  All values are wave-uniform.
+struct GroupInfo {
+    uint32_t inst, first_meshlet, count;  // count = meshlets of this group that exist (<= 64)
+    uint32_t local_group;
+};
+
+__device__ __forceinline__ GroupInfo group_lookup(uint32_t g, const uint2 *__restrict__ ranges,
+                                                  const uint32_t *__restrict__ group_base,
+                                                  const uint32_t *__restrict__ group_inst,
+                                                  uint32_t groups_per_instance, uint32_t uniform_count) {
+    GroupInfo gi;
+    uint32_t moff, mcnt;
+    if (group_inst) {
+        gi.inst = group_inst[g];
+        gi.local_group = g - group_base[gi.inst];
+        const uint2 r = ranges[gi.inst];
+        moff = r.x; mcnt = r.y;
+    } else {
+        gi.inst = g / groups_per_instance;
+        gi.local_group = g - gi.inst * groups_per_instance;
+        moff = 0; mcnt = uniform_count;
+    }
+    gi.first_meshlet = moff + gi.local_group * 64u;
+    const uint32_t left = mcnt - gi.local_group * 64u;
+    gi.count = left < 64u ? left : 64u;
+    return gi;
+}
+
+__device__ __forceinline__ Xform load_xform(const float4 *__restrict__ transforms, uint32_t inst) {
+    const float4 *t = transforms + (size_t)inst * 4;
+    Xform m;
+    m.c0 = t[0]; m.c1 = t[1]; m.c2 = t[2]; m.c3 = t[3];
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered, pass 1: visibility ballots
+__global__ __launch_bounds__(kBlock) void cull_mask_kernel(
+    const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
+    const float4 *__restrict__ transforms, const uint2 *__restrict__ ranges,
+    const uint32_t *__restrict__ group_base, const uint32_t *__restrict__ group_inst,
+    uint32_t groups_per_instance, uint32_t n_groups, uint32_t groups_per_block, ViewConst v,
+    uint64_t *__restrict__ mask, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t s_count[kWaves];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g_begin = blockIdx.x * groups_per_block;
+    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
+    uint32_t count = 0;
+    for (uint32_t g = g_begin + wave; g < g_end; g += kWaves) {
+        const GroupInfo gi = group_lookup(g, ranges, group_base, group_inst, groups_per_instance, v.uniform_count);
+        const Xform m = load_xform(transforms, gi.inst);
+        bool vis = false;
+        if (lane < gi.count) {
+            const uint32_t id = gi.first_meshlet + lane;
+            vis = pair_visible(v, m, cone_axis_w[id], centre_radius[id]);
+        }
+        const uint64_t ballot = __ballot(vis);
+        if (lane == 0) mask[g] = ballot;
+        count += (uint32_t)__popcll(ballot);
+    }
+    if (lane == 0) s_count[wave] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
+// prefix and writes the workgroup total to *total_out (uniform).
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s_wave /*[kWaves]*/, uint32_t *total_out) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+        const uint32_t t = s_wave[w];
+        if ((uint32_t)w < wave) wave_base += t;
+        total += t;
+    }
+    *total_out = total;
+    __syncthreads();  // s_wave may be reused by the caller's next scan
+    return wave_base + incl - x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered, pass 2: scatter.  Same group partition as pass 1.
+__global__ __launch_bounds__(kBlock) void compact_kernel(
+    const uint64_t *__restrict__ mask, const uint32_t *__restrict__ block_counts,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ group_base,
+    const uint32_t *__restrict__ group_inst, uint32_t groups_per_instance,
+    uint32_t n_groups, uint32_t groups_per_block, mcull_visible *__restrict__ list, uint64_t capacity,
+    uint32_t *__restrict__ inst_first, uint64_t *__restrict__ total) {
+    __shared__ uint64_t s_word[kBlock];
+    __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ unsigned long long s_sum[kWaves];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // base of this workgroup = sum of the visible counts of all lower workgroups
+    unsigned long long part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += block_counts[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) s_sum[wave] = part;
+    __syncthreads();
+    unsigned long long running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + block_counts[blockIdx.x];
+
+    const uint32_t g_begin = blockIdx.x * groups_per_block;
+    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
+    for (uint32_t tile = g_begin; tile < g_end; tile += kBlock) {
+        const uint32_t g = tile + threadIdx.x;
+        uint64_t word = 0;
+        uint32_t inst = 0, first = 0, is_first_group = 0;
+        if (g < g_end) {
+            word = mask[g];
+            uint32_t lg, moff;
+            if (group_inst) {
+                inst = group_inst[g];
+                lg = g - group_base[inst];
+                moff = ranges[inst].x;
+            } else {
+                inst = g / groups_per_instance;
+                lg = g - inst * groups_per_instance;
+                moff = 0;
+            }
+            first = moff + lg * 64u;
+            is_first_group = (lg == 0u);
+        }
+        uint32_t tile_total;
+        const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(word), s_wave, &tile_total);
+        s_word[threadIdx.x] = word;
+        s_off[threadIdx.x] = excl;
+        s_inst[threadIdx.x] = inst;
+        s_first[threadIdx.x] = first;
+        // firstTask of an instance = list offset of its first group (exclusive scan in instance order)
+        if (g < g_end && is_first_group) inst_first[inst] = (uint32_t)(running + excl);
+        __syncthreads();
+        const uint32_t n_tile = min((uint32_t)kBlock, g_end - tile);
+        for (uint32_t j = wave; j < n_tile; j += kWaves) {
+            const uint64_t w = s_word[j];
+            if (w == 0) continue;
+            const unsigned long long base = running + s_off[j];
+            if ((w >> lane) & 1ull) {
+                const unsigned long long slot = base + (unsigned long long)__popcll(w & ((1ull << lane) - 1ull));
+                if (slot < capacity) {
+                    mcull_visible e;
+                    e.drawID = s_inst[j];
+                    e.meshletID = s_first[j] + lane;
+                    list[slot] = e;
+                }
+            }
+        }
+        running += tile_total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-instance indirect commands (createIndirectBuffer, Engine.cpp:1466-1484, made dynamic).
+// ordered mode: inst_first[] holds the list offset of every instance that has meshlets;
+// taskCount_i = firstTask of the next non-empty instance (or the total) - firstTask_i.
+// atomic modes: inst_count[] holds visible_i, firstTask = base.
+__global__ __launch_bounds__(kBlock) void emit_commands_kernel(
+    const uint2 *__restrict__ ranges, uint32_t uniform_count, uint32_t n_instances,
+    const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
+    const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
+    uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_instances) return;
+    unsigned long long base = 0;
+    if (rank_totals)
+        for (uint32_t r = 0; r < rank; r++) base += rank_totals[r];
+    uint32_t task_count, first_task;
+    if (inst_count) {
+        task_count = inst_count[i];
+        first_task = (uint32_t)base;
+    } else {
+        const uint32_t tot = (uint32_t)*total;
+        const uint32_t mine = ranges ? ranges[i].y : uniform_count;
+        uint32_t k = i + 1;
+        while (k < n_instances && (ranges ? ranges[k].y : uniform_count) == 0u) k++;
+        const uint32_t next_first = k < n_instances ? inst_first[k] : tot;
+        const uint32_t my_first = mine ? inst_first[i] : next_first;
+        task_count = next_first - my_first;
+        first_task = my_first + (uint32_t)base;
+    }
+    if (form == MCULL_CMD_NV_TASKS32) task_count = (task_count + 31u) / 32u;
+    uint32_t *out = (uint32_t *)(commands + (size_t)i * stride + offset);
+    out[0] = task_count;
+    out[1] = first_task;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-pass compaction with atomics.  BLOCK = false: one returning atomic per wavefront
+// (ballot -> popcount -> lane 0 atomicAdd -> readfirstlane broadcast -> mbcnt scatter);
+// BLOCK = true: the four waves of a workgroup share one atomic per step.
+template <bool BLOCK>
+__global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
+    const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
+    const float4 *__restrict__ transforms, const uint2 *__restrict__ ranges,
+    const uint32_t *__restrict__ group_base, const uint32_t *__restrict__ group_inst,
+    uint32_t groups_per_instance, uint32_t n_groups, uint32_t groups_per_block, ViewConst v,
+    mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_count,
+    unsigned long long *__restrict__ total, uint64_t *__restrict__ mask) {
+    __shared__ uint32_t s_pop[2][kWaves];
+    __shared__ unsigned long long s_base[2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g_begin = blockIdx.x * groups_per_block;
+    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
+    const uint32_t steps = (g_end > g_begin) ? (g_end - g_begin + kWaves - 1) / kWaves : 0;
+    for (uint32_t it = 0; it < steps; it++) {
+        const uint32_t g = g_begin + it * kWaves + wave;
+        const bool active = g < g_end;
+        bool vis = false;
+        GroupInfo gi;
+        gi.inst = 0; gi.first_meshlet = 0; gi.count = 0; gi.local_group = 0;
+        if (active) {
+            gi = group_lookup(g, ranges, group_base, group_inst, groups_per_instance, v.uniform_count);
+            const Xform m = load_xform(transforms, gi.inst);
+            if (lane < gi.count) {
+                const uint32_t id = gi.first_meshlet + lane;
+                vis = pair_visible(v, m, cone_axis_w[id], centre_radius[id]);
+            }
+        }
+        const uint64_t ballot = __ballot(vis);
+        const uint32_t pop = (uint32_t)__popcll(ballot);
+        if (active && mask && lane == 0) mask[g] = ballot;
+        unsigned long long base = 0;
+        if (BLOCK) {
+            const uint32_t buf = it & 1u;
+            if (lane == 0) s_pop[buf][wave] = pop;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t t = (s_pop[buf][0] + s_pop[buf][1]) + (s_pop[buf][2] + s_pop[buf][3]);
+                s_base[buf] = t ? atomicAdd(total, (unsigned long long)t) : 0ull;
+            }
+            __syncthreads();
+            base = s_base[buf];
+            for (uint32_t w = 0; w < wave; w++) base += s_pop[buf][w];
+        } else if (pop) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(total, (unsigned long long)pop);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+            base = ((unsigned long long)hi << 32) | lo;
+        }
+        if (pop) {
+            if (lane == 0) atomicAdd(&inst_count[gi.inst], pop);
+            if (vis) {
+                const unsigned long long slot = base + (unsigned long long)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (slot < capacity) {
+                    mcull_visible e;
+                    e.drawID = gi.inst;
+                    e.meshletID = gi.first_meshlet + lane;
+                    list[slot] = e;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fill_group_inst_kernel(const uint32_t *__restrict__ group_base,
+                                                                 uint32_t n_instances,
+                                                                 uint32_t *__restrict__ group_inst) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_instances) return;
+    const uint32_t b = group_base[i], e = group_base[i + 1];
+    for (uint32_t g = b; g < e; g++) group_inst[g] = i;
+}
+
+// The literal payload of every 32-wide task workgroup (shader.task:28-35, :103-118) rebuilt from
+// the ballots: payload (draw, wg) takes bits [32*wg, 32*wg+32) of the draw's mask words.
+__global__ __launch_bounds__(kBlock) void task_payload_kernel(const uint64_t *__restrict__ mask,
+                                                              uint32_t groups_per_instance,
+                                                              uint32_t payloads_per_instance, uint64_t n_payloads,
+                                                              mcull_task_payload *__restrict__ out) {
+    const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_payloads) return;
+    const uint32_t draw = (uint32_t)(p / payloads_per_instance);
+    const uint32_t wg = (uint32_t)(p - (uint64_t)draw * payloads_per_instance);
+    const uint64_t word = mask[(uint64_t)draw * groups_per_instance + (wg >> 1)];
+    uint32_t bits = (uint32_t)(word >> ((wg & 1u) * 32u));
+    mcull_task_payload *o = out + p;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < 32; k++) o->meshletIndices[k] = 0;
+    while (bits) {
+        const uint32_t b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        o->meshletIndices[n++] = wg * 32u + b;
+    }
+    o->drawID = draw;
+    o->taskCount = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+uint32_t cull_grid_for(uint64_t n_groups, int cu_count) {
+    // persistent-style grid: up to 8 workgroups of 4 waves per CU, each walking a contiguous
+    // range of groups; never more workgroups than there are 4-group steps.
+    uint64_t want = (n_groups + kWaves - 1) / kWaves;
+    uint64_t cap = (uint64_t)cu_count * 8;
+    uint64_t grid = want < cap ? want : cap;
+    return (uint32_t)(grid ? grid : 1);
+}
+
+static inline uint32_t groups_per_block_for(uint64_t n_groups, uint32_t grid) {
+    return (uint32_t)((n_groups + grid - 1) / grid);
+}
+
+hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *block_counts,
+                            uint32_t grid, hipStream_t st) {
+    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
+    hipLaunchKernelGGL(cull_mask_kernel, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, s.transforms,
+                       s.ranges, s.group_base, s.group_inst, s.groups_per_instance, (uint32_t)s.n_groups, gpb, v, mask,
+                       block_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *block_counts, uint32_t grid,
+                          mcull_visible *list, uint64_t capacity, uint32_t *inst_first, uint64_t *total,
+                          hipStream_t st) {
+    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kBlock), 0, st, mask, block_counts, s.ranges, s.group_base,
+                       s.group_inst, s.groups_per_instance, (uint32_t)s.n_groups, gpb, list, capacity, inst_first,
+                       total);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
+                                const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
+                                uint32_t rank, CmdLayout lay, void *commands, hipStream_t st) {
+    if (s.n_instances == 0) return hipSuccess;
+    const uint32_t grid = (s.n_instances + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, uniform_count, s.n_instances,
+                       inst_first, inst_count, total, rank_totals, rank, lay.stride, lay.offset, lay.form,
+                       (uint8_t *)commands);
+    return hipGetLastError();
+}
+
+hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
+                              uint32_t *inst_count, uint64_t *total, uint64_t *mask, uint32_t grid, bool block_mode,
+                              hipStream_t st) {
+    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
+    if (block_mode)
+        hipLaunchKernelGGL(cull_atomic_kernel<true>, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
+                           s.transforms, s.ranges, s.group_base, s.group_inst, s.groups_per_instance,
+                           (uint32_t)s.n_groups, gpb, v, list, capacity, inst_count, (unsigned long long *)total, mask);
+    else
+        hipLaunchKernelGGL(cull_atomic_kernel<false>, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
+                           s.transforms, s.ranges, s.group_base, s.group_inst, s.groups_per_instance,
+                           (uint32_t)s.n_groups, gpb, v, list, capacity, inst_count, (unsigned long long *)total, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_group_inst(const uint32_t *group_base, uint32_t n_instances, uint32_t *group_inst,
+                                  hipStream_t st) {
+    if (n_instances == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_group_inst_kernel, dim3((n_instances + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       group_base, n_instances, group_inst);
+    return hipGetLastError();
+}
+
+hipError_t launch_task_payloads(const SceneDev &s, const uint64_t *mask, mcull_task_payload *out, uint64_t n_payloads,
+                                uint32_t payloads_per_instance, hipStream_t st) {
+    if (n_payloads == 0) return hipSuccess;
+    hipLaunchKernelGGL(task_payload_kernel, dim3((uint32_t)((n_payloads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       mask, s.groups_per_instance, payloads_per_instance, n_payloads, out);
+    return hipGetLastError();
+}
+
+}  // namespace mcull

@@ -1,0 +1,708 @@
+// C ABI of libmcull (include/mcull.h): context, buffers, host-side uniform math, launch sequencing.
+// No CPU fallback exists anywhere in this library: every entry point that computes runs the
+// gfx950 kernels, and fails with MCULL_E_HIP when no device is usable.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mcull_internal.h"
+
+#define MCULL_VERSION_NUMBER 100
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool owned = true;
+};
+
+struct HizSlot {
+    DevBuf pyramid, table;
+    uint32_t w = 0, h = 0, levels = 0;
+    uint32_t lw[MCULL_MAX_HIZ_LEVELS], lh[MCULL_MAX_HIZ_LEVELS];
+    uint64_t loff[MCULL_MAX_HIZ_LEVELS];
+    uint64_t total_floats = 0;
+    bool built = false;
+};
+
+}  // namespace
+
+struct mcull_ctx {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+
+    // scene
+    DevBuf aos, cone, sphere, vertices, mdata, transforms, ranges, group_base, group_inst;
+    uint64_t n_meshlets = 0, n_vertices = 0, n_words = 0, n_instances = 0;
+    bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
+    uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
+
+    // Hi-Z
+    HizSlot hiz[MCULL_MAX_VIEWS];
+    DevBuf depth_staging, hiz_counter;
+    bool hiz_single_pass = true;
+
+    // cull scratch + outputs
+    DevBuf mask, block_counts, inst_first, inst_count, total, list, commands;
+    // description of the last cull (for rebase / downloads / payloads)
+    struct Last {
+        bool valid = false;
+        mcull::SceneDev scene{};
+        uint32_t uniform_count = 0;
+        uint32_t compaction = 0;
+        mcull::CmdLayout lay{8, 0, 0};
+        mcull_visible *list = nullptr;
+        uint64_t capacity = 0;
+        void *commands = nullptr;
+        bool have_mask = false;
+        uint64_t n_pairs = 0;
+    } last;
+};
+
+namespace {
+
+int fail(mcull_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail((c), MCULL_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(mcull_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    if (b.owned && b.p && b.cap >= bytes) return MCULL_OK;
+    if (b.p && b.owned) {
+        hipError_t e = hipFree(b.p);
+        if (e != hipSuccess) return fail(c, MCULL_E_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    }
+    b.p = nullptr; b.cap = 0; b.owned = true;
+    const size_t want = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, e == hipErrorOutOfMemory ? MCULL_E_NOMEM : MCULL_E_HIP, "hipMalloc(%zu) failed: %s", want,
+                    hipGetErrorString(e));
+    }
+    b.cap = want;
+    return MCULL_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p && b.owned) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0; b.owned = true;
+}
+
+int copy_in(mcull_ctx *c, void *dst, const void *src, size_t bytes, int mem) {
+    if (bytes == 0) return MCULL_OK;
+    if (mem == MCULL_MEM_HOST) {
+        // the caller may free / reuse a host pointer as soon as the call returns
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return MCULL_OK;
+}
+
+// ---- uniform host math, IEEE binary32, fixed association order, no fused multiply-add ----
+inline float Ec(const float *m, int r, int col) { return m[4 * col + r]; }
+
+// proj * view (shader.task:60 evaluates (proj*view)*v): column c of the product is
+// ((P[0]*V[c][0] + P[1]*V[c][1]) + P[2]*V[c][2]) + P[3]*V[c][3]
+void mat4_mul(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++)
+            r[4 * col + row] = ((Ec(a, row, 0) * Ec(b, 0, col) + Ec(a, row, 1) * Ec(b, 1, col)) +
+                                Ec(a, row, 2) * Ec(b, 2, col)) + Ec(a, row, 3) * Ec(b, 3, col);
+    std::memcpy(out, r, sizeof r);
+}
+
+// inverse(view)[3].xyz (shader.task:88-89) by cofactor expansion: inv(r,c) = cof(c,r) * (1/det);
+// 3x3 minors expand along their first row, the determinant along row 0, sums left to right.
+void camera_position(const float *view, float cam[3]) {
+    float cof[4][4];
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) {
+            float e[9];
+            int k = 0;
+            for (int r = 0; r < 4; r++) {
+                if (r == i) continue;
+                for (int col = 0; col < 4; col++) {
+                    if (col == j) continue;
+                    e[k++] = Ec(view, r, col);
+                }
+            }
+            const float minor = (e[0] * (e[4] * e[8] - e[5] * e[7]) - e[1] * (e[3] * e[8] - e[5] * e[6])) +
+                                e[2] * (e[3] * e[7] - e[4] * e[6]);
+            cof[i][j] = ((i + j) & 1) ? -minor : minor;
+        }
+    }
+    const float det = ((Ec(view, 0, 0) * cof[0][0] + Ec(view, 0, 1) * cof[0][1]) + Ec(view, 0, 2) * cof[0][2]) +
+                      Ec(view, 0, 3) * cof[0][3];
+    const float inv_det = 1.0f / det;
+    for (int r = 0; r < 3; r++) cam[r] = cof[3][r] * inv_det;  // inv(r, 3) = cof(3, r) / det
+}
+
+uint32_t level_count(uint32_t w, uint32_t h) {
+    uint32_t m = w > h ? w : h, l = 0;
+    while (m > 1) { m >>= 1; l++; }
+    return l + 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcull_version(void) { return MCULL_VERSION_NUMBER; }
+
+const char *mcull_status_string(int status) {
+    switch (status) {
+        case MCULL_OK: return "MCULL_OK";
+        case MCULL_E_INVALID: return "MCULL_E_INVALID";
+        case MCULL_E_HIP: return "MCULL_E_HIP";
+        case MCULL_E_CAPACITY: return "MCULL_E_CAPACITY";
+        case MCULL_E_STATE: return "MCULL_E_STATE";
+        case MCULL_E_NOMEM: return "MCULL_E_NOMEM";
+        default: return "MCULL_E_UNKNOWN";
+    }
+}
+
+const char *mcull_last_error(const mcull_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
+    if (!out) return MCULL_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MCULL_E_HIP;
+    if (device_ordinal < 0 || device_ordinal >= count) return MCULL_E_INVALID;
+    mcull_ctx *c = new (std::nothrow) mcull_ctx();
+    if (!c) return MCULL_E_NOMEM;
+    c->device = device_ordinal;
+    c->stream = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return MCULL_E_HIP;
+    }
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char *two_pass = std::getenv("MCULL_HIZ_TWO_PASS");
+    c->hiz_single_pass = !(two_pass && two_pass[0] == '1');
+    *out = c;
+    return MCULL_OK;
+}
+
+int mcull_destroy(mcull_ctx *c) {
+    if (!c) return MCULL_E_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->ranges,
+                      &c->group_base, &c->group_inst, &c->depth_staging, &c->hiz_counter, &c->mask, &c->block_counts,
+                      &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands};
+    for (DevBuf *b : bufs) release(*b);
+    for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return MCULL_OK;
+}
+
+int mcull_synchronize(mcull_ctx *c) {
+    if (!c) return MCULL_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCULL_OK;
+}
+
+// ------------------------------------------------------------------------------------ uploads
+
+int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t count, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if (!meshlets && count) return fail(c, MCULL_E_INVALID, "meshlets is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->aos, count * sizeof(mcull_meshlet)))) return rc;
+    if (!c->cone.owned) c->cone = DevBuf();
+    if (!c->sphere.owned) c->sphere = DevBuf();
+    if ((rc = ensure(c, c->cone, count * 16))) return rc;
+    if ((rc = ensure(c, c->sphere, count * 16))) return rc;
+    if ((rc = copy_in(c, c->aos.p, meshlets, count * sizeof(mcull_meshlet), mem))) return rc;
+    HIPCHK(c, mcull::launch_split_meshlets((const mcull_meshlet *)c->aos.p, count, (float4 *)c->cone.p,
+                                           (float4 *)c->sphere.p, c->stream));
+    c->n_meshlets = count;
+    c->have_aos = true;
+    c->have_bounds = true;
+    c->last.valid = false;
+    return MCULL_OK;
+}
+
+int mcull_upload_bounds_soa(mcull_ctx *c, const float *cone_axis_w, const float *centre_radius, uint64_t count,
+                            int mem, int adopt) {
+    if (!c) return MCULL_E_INVALID;
+    if ((!cone_axis_w || !centre_radius) && count) return fail(c, MCULL_E_INVALID, "null bounds stream");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (adopt && mem == MCULL_MEM_DEVICE) {
+        if ((reinterpret_cast<uintptr_t>(cone_axis_w) | reinterpret_cast<uintptr_t>(centre_radius)) & 15u)
+            return fail(c, MCULL_E_INVALID, "adopted bounds streams must be 16-byte aligned");
+        release(c->cone); release(c->sphere);
+        c->cone.p = const_cast<float *>(cone_axis_w); c->cone.cap = count * 16; c->cone.owned = false;
+        c->sphere.p = const_cast<float *>(centre_radius); c->sphere.cap = count * 16; c->sphere.owned = false;
+    } else {
+        int rc;
+        if (!c->cone.owned) c->cone = DevBuf();
+        if (!c->sphere.owned) c->sphere = DevBuf();
+        if ((rc = ensure(c, c->cone, count * 16))) return rc;
+        if ((rc = ensure(c, c->sphere, count * 16))) return rc;
+        if ((rc = copy_in(c, c->cone.p, cone_axis_w, count * 16, mem))) return rc;
+        if ((rc = copy_in(c, c->sphere.p, centre_radius, count * 16, mem))) return rc;
+    }
+    c->n_meshlets = count;
+    c->have_aos = false;
+    c->have_bounds = true;
+    c->last.valid = false;
+    return MCULL_OK;
+}
+
+int mcull_upload_geometry(mcull_ctx *c, const mcull_vertex *vertices, uint64_t vertex_count,
+                          const uint32_t *meshlet_data, uint64_t word_count, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if ((!vertices && vertex_count) || (!meshlet_data && word_count)) return fail(c, MCULL_E_INVALID, "null geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->vertices, vertex_count * sizeof(mcull_vertex)))) return rc;
+    if ((rc = ensure(c, c->mdata, word_count * 4 + 4))) return rc;
+    if ((rc = copy_in(c, c->vertices.p, vertices, vertex_count * sizeof(mcull_vertex), mem))) return rc;
+    if ((rc = copy_in(c, c->mdata.p, meshlet_data, word_count * 4, mem))) return rc;
+    c->n_vertices = vertex_count;
+    c->n_words = word_count;
+    c->have_geometry = true;
+    return MCULL_OK;
+}
+
+int mcull_compute_bounds(mcull_ctx *c) {
+    if (!c) return MCULL_E_INVALID;
+    if (!c->have_aos) return fail(c, MCULL_E_STATE, "mcull_upload_meshlets has not been called");
+    if (!c->have_geometry) return fail(c, MCULL_E_STATE, "mcull_upload_geometry has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    // Host-side shape check: every meshlet's block must lie inside meshletData and every global
+    // vertex id inside the vertex array; the kernel indexes without bounds checks.
+    {
+        std::vector<mcull_meshlet> ml(c->n_meshlets);
+        std::vector<uint32_t> md(c->n_words);
+        HIPCHK(c, hipMemcpyAsync(ml.data(), c->aos.p, c->n_meshlets * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(md.data(), c->mdata.p, c->n_words * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < c->n_meshlets; i++) {
+            const mcull_meshlet &m = ml[i];
+            const uint64_t words = (uint64_t)m.vertexCount + ((uint64_t)m.triangleCount * 3 + 3) / 4;
+            if (m.vertexCount > 64 || m.triangleCount > 124 || (uint64_t)m.dataOffset + words > c->n_words)
+                return fail(c, MCULL_E_INVALID, "meshlet %llu: counts/dataOffset outside meshletData", (unsigned long long)i);
+            const uint8_t *loc = reinterpret_cast<const uint8_t *>(md.data() + m.dataOffset + m.vertexCount);
+            for (uint32_t v = 0; v < m.vertexCount; v++)
+                if (md[m.dataOffset + v] >= c->n_vertices)
+                    return fail(c, MCULL_E_INVALID, "meshlet %llu: vertex id out of range", (unsigned long long)i);
+            for (uint32_t t = 0; t < (uint32_t)m.triangleCount * 3; t++)
+                if (loc[t] >= m.vertexCount)
+                    return fail(c, MCULL_E_INVALID, "meshlet %llu: local index out of range", (unsigned long long)i);
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mcull::launch_bounds((const mcull_vertex *)c->vertices.p, (const uint32_t *)c->mdata.p,
+                                   (mcull_meshlet *)c->aos.p, c->n_meshlets, (float4 *)c->cone.p, (float4 *)c->sphere.p,
+                                   c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    c->have_bounds = true;
+    return MCULL_OK;
+}
+
+int mcull_download_meshlets(mcull_ctx *c, mcull_meshlet *out, uint64_t count) {
+    if (!c || !out) return MCULL_E_INVALID;
+    if (!c->have_aos) return fail(c, MCULL_E_STATE, "no AoS meshlets in this context");
+    if (count > c->n_meshlets) return fail(c, MCULL_E_INVALID, "count exceeds uploaded meshlets");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->aos.p, count * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCULL_OK;
+}
+
+int mcull_upload_transforms(mcull_ctx *c, const mcull_transform *transforms, uint64_t count, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if (!transforms && count) return fail(c, MCULL_E_INVALID, "transforms is null");
+    if (count >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "too many instances");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->transforms, count * sizeof(mcull_transform)))) return rc;
+    if ((rc = copy_in(c, c->transforms.p, transforms, count * sizeof(mcull_transform), mem))) return rc;
+    c->n_instances = count;
+    c->last.valid = false;
+    return MCULL_OK;
+}
+
+int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, const uint32_t *meshlet_count,
+                              uint64_t n_instances) {
+    if (!c) return MCULL_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->last.valid = false;
+    if (!meshlet_offset || !meshlet_count) {
+        c->have_ranges = false;
+        return MCULL_OK;
+    }
+    if (n_instances >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "too many instances");
+    std::vector<uint32_t> rg(2 * n_instances), base(n_instances + 1);
+    uint64_t groups = 0, pairs = 0, max_end = 0;
+    for (uint64_t i = 0; i < n_instances; i++) {
+        rg[2 * i] = meshlet_offset[i];
+        rg[2 * i + 1] = meshlet_count[i];
+        base[i] = (uint32_t)groups;
+        groups += ((uint64_t)meshlet_count[i] + 63) / 64;
+        pairs += meshlet_count[i];
+        const uint64_t end = (uint64_t)meshlet_offset[i] + meshlet_count[i];
+        if (end > max_end) max_end = end;
+        if (groups >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "more than 2^32 meshlet groups");
+    }
+    base[n_instances] = (uint32_t)groups;
+    int rc;
+    if ((rc = ensure(c, c->ranges, rg.size() * 4))) return rc;
+    if ((rc = ensure(c, c->group_base, base.size() * 4))) return rc;
+    if ((rc = ensure(c, c->group_inst, groups * 4))) return rc;
+    if ((rc = copy_in(c, c->ranges.p, rg.data(), rg.size() * 4, MCULL_MEM_HOST))) return rc;
+    if ((rc = copy_in(c, c->group_base.p, base.data(), base.size() * 4, MCULL_MEM_HOST))) return rc;
+    HIPCHK(c, mcull::launch_fill_group_inst((const uint32_t *)c->group_base.p, (uint32_t)n_instances,
+                                            (uint32_t *)c->group_inst.p, c->stream));
+    c->have_ranges = true;
+    c->ranged_groups = groups;
+    c->ranged_pairs = pairs;
+    c->ranged_max_end = max_end;
+    c->ranged_instances = n_instances;
+    return MCULL_OK;
+}
+
+// ------------------------------------------------------------------------------------ Hi-Z
+
+uint32_t mcull_hiz_level_count(uint32_t width, uint32_t height) { return level_count(width, height); }
+
+uint64_t mcull_hiz_layout(uint32_t width, uint32_t height, uint32_t *levels, uint32_t lw[MCULL_MAX_HIZ_LEVELS],
+                          uint32_t lh[MCULL_MAX_HIZ_LEVELS], uint64_t loff[MCULL_MAX_HIZ_LEVELS]) {
+    uint32_t n = level_count(width, height);
+    if (n > MCULL_MAX_HIZ_LEVELS) n = MCULL_MAX_HIZ_LEVELS;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t w = (width >> i) ? (width >> i) : 1u, h = (height >> i) ? (height >> i) : 1u;
+        if (lw) lw[i] = w;
+        if (lh) lh[i] = h;
+        if (loff) loff[i] = total;
+        total += (uint64_t)w * h;
+    }
+    if (levels) *levels = n;
+    return total;
+}
+
+int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t width, uint32_t height, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if (view >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view slot %u out of range", view);
+    if (!depth || width == 0 || height == 0) return fail(c, MCULL_E_INVALID, "empty depth image");
+    if (level_count(width, height) > MCULL_MAX_HIZ_LEVELS) return fail(c, MCULL_E_INVALID, "depth image too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    HizSlot &s = c->hiz[view];
+    uint32_t levels;
+    const uint64_t total = mcull_hiz_layout(width, height, &levels, s.lw, s.lh, s.loff);
+    if (total >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "pyramid exceeds 2^32 texels");
+    int rc;
+    if ((rc = ensure(c, s.pyramid, total * 4))) return rc;
+    if ((rc = ensure(c, s.table, 48 * 4))) return rc;
+    if ((rc = ensure(c, c->hiz_counter, 256))) return rc;
+    if (!s.built || s.w != width || s.h != height) {
+        uint32_t tbl[48];
+        std::memset(tbl, 0, sizeof tbl);
+        for (uint32_t i = 0; i < levels; i++) { tbl[i] = s.lw[i]; tbl[16 + i] = s.lh[i]; tbl[32 + i] = (uint32_t)s.loff[i]; }
+        if ((rc = copy_in(c, s.table.p, tbl, sizeof tbl, MCULL_MEM_HOST))) return rc;
+    }
+    const float *src = depth;
+    if (mem == MCULL_MEM_HOST) {
+        if ((rc = ensure(c, c->depth_staging, (size_t)width * height * 4))) return rc;
+        if ((rc = copy_in(c, c->depth_staging.p, depth, (size_t)width * height * 4, MCULL_MEM_HOST))) return rc;
+        src = (const float *)c->depth_staging.p;
+    }
+    s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
+                                (uint32_t *)c->hiz_counter.p, c->hiz_single_pass, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    s.built = true;
+    return MCULL_OK;
+}
+
+int mcull_hiz_pyramid(mcull_ctx *c, uint32_t view, const float **device_ptr, uint64_t *float_count) {
+    if (!c || view >= MCULL_MAX_VIEWS) return MCULL_E_INVALID;
+    if (!c->hiz[view].built) return fail(c, MCULL_E_STATE, "no pyramid built for view %u", view);
+    if (device_ptr) *device_ptr = (const float *)c->hiz[view].pyramid.p;
+    if (float_count) *float_count = c->hiz[view].total_floats;
+    return MCULL_OK;
+}
+
+int mcull_hiz_download_level(mcull_ctx *c, uint32_t view, uint32_t level, float *out) {
+    if (!c || !out || view >= MCULL_MAX_VIEWS) return MCULL_E_INVALID;
+    HizSlot &s = c->hiz[view];
+    if (!s.built) return fail(c, MCULL_E_STATE, "no pyramid built for view %u", view);
+    if (level >= s.levels) return fail(c, MCULL_E_INVALID, "level %u of %u", level, s.levels);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, (const float *)s.pyramid.p + s.loff[level], (size_t)s.lw[level] * s.lh[level] * 4,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCULL_OK;
+}
+
+// ------------------------------------------------------------------------------------ cull
+
+int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
+    if (!c) return MCULL_E_INVALID;
+    if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
+    if (!c->have_bounds) return fail(c, MCULL_E_STATE, "no meshlet bounds uploaded");
+    mcull_cull_params p;
+    std::memset(&p, 0, sizeof p);
+    if (params) p = *params;
+    else { p.tests = MCULL_TEST_ALL; p.compaction = MCULL_COMPACT_ORDERED; }
+    if (p.cmd_stride == 0) p.cmd_stride = 8;
+    if (p.tests & ~MCULL_TEST_ALL) return fail(c, MCULL_E_INVALID, "unknown test bits 0x%x", p.tests);
+    if (p.compaction > MCULL_COMPACT_BLOCK_ATOMIC) return fail(c, MCULL_E_INVALID, "unknown compaction %u", p.compaction);
+    if (p.cmd_form > MCULL_CMD_NV_TASKS32) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
+    if (p.cmd_form == MCULL_CMD_NV_TASKS32 && p.compaction != MCULL_COMPACT_ORDERED)
+        return fail(c, MCULL_E_INVALID, "TASKS32 commands need ordered compaction");
+    if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + 8u > p.cmd_stride)
+        return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+8 <= stride");
+    if ((p.tests & MCULL_TEST_HIZ) && (p.hiz_view >= MCULL_MAX_VIEWS || !c->hiz[p.hiz_view].built))
+        return fail(c, MCULL_E_STATE, "Hi-Z test requested but no pyramid built for view %u", p.hiz_view);
+    HIPCHK(c, hipSetDevice(c->device));
+
+    mcull::SceneDev s{};
+    s.cone_axis_w = (const float4 *)c->cone.p;
+    s.centre_radius = (const float4 *)c->sphere.p;
+    s.transforms = (const float4 *)c->transforms.p;
+    s.n_instances = (uint32_t)c->n_instances;
+    uint64_t n_pairs;
+    uint32_t uniform_count = 0;
+    if (c->have_ranges) {
+        if (c->ranged_instances != c->n_instances)
+            return fail(c, MCULL_E_STATE, "instance ranges cover %llu instances, transforms %llu",
+                        (unsigned long long)c->ranged_instances, (unsigned long long)c->n_instances);
+        if (c->ranged_max_end > c->n_meshlets) return fail(c, MCULL_E_INVALID, "an instance range exceeds the meshlet array");
+        s.ranges = (const uint2 *)c->ranges.p;
+        s.group_base = (const uint32_t *)c->group_base.p;
+        s.group_inst = (const uint32_t *)c->group_inst.p;
+        s.groups_per_instance = 0;
+        s.n_groups = c->ranged_groups;
+        n_pairs = c->ranged_pairs;
+    } else {
+        uniform_count = g->meshletCount;  // shader.task:85
+        if (uniform_count > c->n_meshlets) return fail(c, MCULL_E_INVALID, "globals.meshletCount exceeds uploaded meshlets");
+        s.groups_per_instance = (uniform_count + 63u) / 64u;
+        s.n_groups = (uint64_t)s.groups_per_instance * c->n_instances;
+        n_pairs = (uint64_t)uniform_count * c->n_instances;
+        if (s.n_groups >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "more than 2^32 meshlet groups");
+    }
+
+    mcull::ViewConst v{};
+    std::memcpy(v.frustum, g->frustum, sizeof v.frustum);
+    mat4_mul(g->proj, g->view, v.vp);
+    camera_position(g->view, v.cam);
+    v.proj11 = g->proj[5];
+    v.tests = p.tests;
+    v.uniform_count = uniform_count;
+    if (p.tests & MCULL_TEST_HIZ) {
+        const HizSlot &hs = c->hiz[p.hiz_view];
+        v.tex_max = (float)(hs.w > hs.h ? hs.w : hs.h);
+        v.levels = hs.levels;
+        v.level_table = (const uint32_t *)hs.table.p;
+        v.pyramid = (const float *)hs.pyramid.p;
+    }
+
+    int rc;
+    const bool want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
+    if (want_mask && (rc = ensure(c, c->mask, s.n_groups * 8))) return rc;
+    if ((rc = ensure(c, c->total, 256))) return rc;
+    mcull_visible *list = p.list;
+    uint64_t capacity = p.list_capacity;
+    if (!list) {
+        if (capacity == 0) capacity = n_pairs;
+        if ((rc = ensure(c, c->list, capacity * sizeof(mcull_visible)))) return rc;
+        list = (mcull_visible *)c->list.p;
+    }
+    void *commands = p.commands;
+    if (!commands) {
+        const size_t bytes = (size_t)c->n_instances * p.cmd_stride;
+        const bool fresh = !c->commands.p || c->commands.cap < bytes;
+        if ((rc = ensure(c, c->commands, bytes))) return rc;
+        // bytes of a record outside the 8-byte command are never written by the kernels
+        if (fresh) HIPCHK(c, hipMemsetAsync(c->commands.p, 0, c->commands.cap, c->stream));
+        commands = c->commands.p;
+    }
+    const uint32_t grid = mcull::cull_grid_for(s.n_groups, c->cu_count);
+    const mcull::CmdLayout lay{p.cmd_stride, p.cmd_offset, p.cmd_form};
+
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (s.n_groups == 0) {
+        HIPCHK(c, hipMemsetAsync(c->total.p, 0, 8, c->stream));
+        if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
+                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+    } else if (p.compaction == MCULL_COMPACT_ORDERED) {
+        if ((rc = ensure(c, c->block_counts, (size_t)grid * 4))) return rc;
+        if ((rc = ensure(c, c->inst_first, (c->n_instances + 1) * 4))) return rc;
+        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->block_counts.p, grid, c->stream));
+        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->block_counts.p, grid, list,
+                                        capacity, (uint32_t *)c->inst_first.p, (uint64_t *)c->total.p, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
+                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+    } else {
+        if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->total.p, 0, 256, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_cull_atomic(s, v, list, capacity, (uint32_t *)c->inst_count.p, (uint64_t *)c->total.p,
+                                            p.write_mask ? (uint64_t *)c->mask.p : nullptr, grid,
+                                            p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
+                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+
+    c->last.valid = true;
+    c->last.scene = s;
+    c->last.uniform_count = uniform_count;
+    c->last.compaction = p.compaction;
+    c->last.lay = lay;
+    c->last.list = list;
+    c->last.capacity = capacity;
+    c->last.commands = commands;
+    c->last.have_mask = want_mask && s.n_groups > 0;
+    c->last.n_pairs = n_pairs;
+    if (result) {
+        result->list = list;
+        result->commands = commands;
+        result->total = (const uint64_t *)c->total.p;
+        result->mask = c->last.have_mask ? (const uint64_t *)c->mask.p : nullptr;
+        result->n_groups = s.n_groups;
+        result->n_pairs = n_pairs;
+    }
+    return MCULL_OK;
+}
+
+int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t rank) {
+    if (!c) return MCULL_E_INVALID;
+    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result to rebase");
+    if (!device_totals && rank) return fail(c, MCULL_E_INVALID, "device_totals is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool ordered = c->last.compaction == MCULL_COMPACT_ORDERED && c->last.scene.n_groups > 0;
+    HIPCHK(c, mcull::launch_emit_commands(c->last.scene, c->last.uniform_count,
+                                          ordered ? (const uint32_t *)c->inst_first.p : nullptr,
+                                          ordered ? nullptr : (const uint32_t *)c->inst_count.p,
+                                          (const uint64_t *)c->total.p, device_totals, rank, c->last.lay,
+                                          c->last.commands, c->stream));
+    return MCULL_OK;
+}
+
+uint64_t mcull_task_payload_count(const mcull_ctx *c) {
+    if (!c || !c->last.valid || c->last.scene.ranges) return 0;
+    return (uint64_t)((c->last.uniform_count + 31u) / 32u) * c->last.scene.n_instances;
+}
+
+int mcull_emit_task_payloads(mcull_ctx *c, mcull_task_payload *out) {
+    if (!c || !out) return MCULL_E_INVALID;
+    if (!c->last.valid || !c->last.have_mask) return fail(c, MCULL_E_STATE, "no cull result with a visibility mask");
+    if (c->last.scene.ranges) return fail(c, MCULL_E_INVALID, "task payloads need a uniform meshlet count");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t ppi = (c->last.uniform_count + 31u) / 32u;
+    HIPCHK(c, mcull::launch_task_payloads(c->last.scene, (const uint64_t *)c->mask.p, out,
+                                          (uint64_t)ppi * c->last.scene.n_instances, ppi, c->stream));
+    return MCULL_OK;
+}
+
+int mcull_download_count(mcull_ctx *c, uint64_t *total) {
+    if (!c || !total) return MCULL_E_INVALID;
+    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(total, c->total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCULL_OK;
+}
+
+int mcull_download_list(mcull_ctx *c, mcull_visible *out, uint64_t capacity, uint64_t *total) {
+    if (!c) return MCULL_E_INVALID;
+    uint64_t n = 0;
+    int rc = mcull_download_count(c, &n);
+    if (rc) return rc;
+    if (total) *total = n;
+    if (n > c->last.capacity)
+        return fail(c, MCULL_E_CAPACITY, "visible list needs %llu entries, device capacity is %llu",
+                    (unsigned long long)n, (unsigned long long)c->last.capacity);
+    if (n > capacity)
+        return fail(c, MCULL_E_CAPACITY, "visible list needs %llu entries, host capacity is %llu",
+                    (unsigned long long)n, (unsigned long long)capacity);
+    if (n && !out) return fail(c, MCULL_E_INVALID, "out is null");
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(out, c->last.list, n * sizeof(mcull_visible), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MCULL_OK;
+}
+
+int mcull_download_commands(mcull_ctx *c, void *out, uint64_t bytes) {
+    if (!c || !out) return MCULL_E_INVALID;
+    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    const uint64_t have = (uint64_t)c->last.scene.n_instances * c->last.lay.stride;
+    if (bytes > have) return fail(c, MCULL_E_INVALID, "requested %llu bytes of %llu", (unsigned long long)bytes, (unsigned long long)have);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) {
+        HIPCHK(c, hipMemcpyAsync(out, c->last.commands, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MCULL_OK;
+}
+
+int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
+    if (!c || !out) return MCULL_E_INVALID;
+    if (!c->last.valid || !c->last.have_mask) return fail(c, MCULL_E_STATE, "no visibility mask kept");
+    if (words > c->last.scene.n_groups) return fail(c, MCULL_E_INVALID, "requested more words than groups");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (words) {
+        HIPCHK(c, hipMemcpyAsync(out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MCULL_OK;
+}
+
+int mcull_last_kernel_ms(mcull_ctx *c, float *ms) {
+    if (!c || !ms) return MCULL_E_INVALID;
+    if (!c->timed) return fail(c, MCULL_E_STATE, "nothing has been timed yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MCULL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Internal declarations shared by the HIP translation units of libmcull (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcull.h"
+
+namespace mcull {
+
+// Per-view constants handed to the cull kernels by value (kernarg segment -> SGPRs).
+// Everything here is uniform over the launch; it is the device-side image of the
+// reference's 212-byte Globals push-constant block (shaders/common.h:7-12) with the two
+// uniform expressions of shader.task hoisted to the host: inverse(view)[3].xyz
+// (shader.task:88-89) and proj*view (shader.task:60).
+struct ViewConst {
+    float frustum[5][4];
+    float vp[16];        // column-major proj*view
+    float cam[3];
+    float proj11;        // globals.proj[1][1]
+    float tex_max;       // max(textureSize(pyramid, 0))
+    uint32_t levels;
+    uint32_t tests;      // MCULL_TEST_*
+    uint32_t uniform_count;  // meshlets per instance when there are no per-instance ranges
+    // device table of 3 x 16 uint32: level widths, level heights, float offset of each level in
+    // the flat pyramid (indexed per lane by the selected mip level)
+    const uint32_t *level_table;
+    const float *pyramid;
+};
+
+// Scene pointers of one cull launch.
+struct SceneDev {
+    const float4 *cone_axis_w;    // {axis.xyz, coneW} per meshlet
+    const float4 *centre_radius;  // {centre.xyz, radius} per meshlet
+    const float4 *transforms;     // 4 x float4 (column-major mat4) per instance
+    const uint2 *ranges;          // {meshletOffset, meshletCount} per instance, or nullptr
+    const uint32_t *group_base;   // exclusive prefix of ceil(count/64) per instance (I+1), or nullptr
+    const uint32_t *group_inst;   // instance of every 64-meshlet group, or nullptr
+    uint32_t n_instances;
+    uint32_t groups_per_instance; // uniform case
+    uint64_t n_groups;
+};
+
+struct CmdLayout {
+    uint32_t stride, offset, form;
+};
+
+// ---- launchers (each returns the hipError_t of the launch) ----
+hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *block_counts,
+                            uint32_t grid, hipStream_t st);
+hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *block_counts, uint32_t grid,
+                          mcull_visible *list, uint64_t capacity, uint32_t *inst_first, uint64_t *total,
+                          hipStream_t st);
+hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
+                                const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
+                                uint32_t rank, CmdLayout lay, void *commands, hipStream_t st);
+hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
+                              uint32_t *inst_count, uint64_t *total, uint64_t *mask, uint32_t grid, bool block_mode,
+                              hipStream_t st);
+hipError_t launch_fill_group_inst(const uint32_t *group_base, uint32_t n_instances, uint32_t *group_inst,
+                                  hipStream_t st);
+hipError_t launch_task_payloads(const SceneDev &s, const uint64_t *mask, mcull_task_payload *out, uint64_t n_payloads,
+                                uint32_t payloads_per_instance, hipStream_t st);
+
+hipError_t launch_split_meshlets(const mcull_meshlet *aos, uint64_t n, float4 *cone_axis_w, float4 *centre_radius,
+                                 hipStream_t st);
+hipError_t launch_bounds(const mcull_vertex *vertices, const uint32_t *meshlet_data, mcull_meshlet *meshlets,
+                         uint64_t n, float4 *cone_axis_w, float4 *centre_radius, hipStream_t st);
+
+hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
+                      const uint32_t *level_table, uint32_t *counter, bool single_pass, hipStream_t st);
+
+uint32_t cull_grid_for(uint64_t n_groups, int cu_count);
+
+}  // namespace mcull
