@@ -122,17 +122,16 @@ typedef struct mcull_task_payload {
                                        per-instance taskCount exact, firstTask = 0 for every draw */
 #define MCULL_COMPACT_BLOCK_ATOMIC 2 /* single pass, one atomic per workgroup batch; as above     */
 
-/* indirect-command forms written by mcull_cull / mcull_rebase_commands */
-#define MCULL_CMD_NV_MESHLETS 0 /* {taskCount = visible_i, firstTask}: one mesh workgroup per meshlet */
-#define MCULL_CMD_NV_TASKS32 1  /* {taskCount = ceil(visible_i/32), firstTask/32 rounded}: pass-through
-                                   task stage, list padded per draw to a multiple of 32 (unsupported
-                                   with atomic compaction)                                            */
+/* indirect-command form written by mcull_cull / mcull_rebase_commands: the reference's NV record
+ * {taskCount = visible_i, firstTask} - one mesh workgroup per surviving meshlet, reading
+ * list[firstTask + gl_WorkGroupID.x] (other values are reserved). */
+#define MCULL_CMD_NV_MESHLETS 0
 
 typedef struct mcull_cull_params {
     uint32_t tests;          /* MCULL_TEST_* bits                                      */
     uint32_t compaction;     /* MCULL_COMPACT_*                                        */
     uint32_t hiz_view;       /* which pyramid slot the Hi-Z test samples               */
-    uint32_t cmd_form;       /* MCULL_CMD_*                                            */
+    uint32_t cmd_form;       /* MCULL_CMD_NV_MESHLETS                                  */
     uint32_t cmd_stride;     /* bytes between commands; 0 -> 8                         */
     uint32_t cmd_offset;     /* byte offset of the command in a record; 28/20 = DrawIndirect */
     uint32_t write_mask;     /* non-zero: keep the 1-bit-per-pair visibility mask      */
@@ -141,6 +140,7 @@ typedef struct mcull_cull_params {
     mcull_visible *list;     /* capacity list_capacity entries                         */
     uint64_t list_capacity;
     void *commands;          /* n_instances records of cmd_stride bytes                */
+    uint64_t *total;         /* one uint64: the visible count (e.g. the send buffer of an all-gather) */
 } mcull_cull_params;
 
 typedef struct mcull_cull_result {

@@ -45,7 +45,7 @@ OK, E_INVALID, E_HIP, E_CAPACITY, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 TEST_FRUSTUM, TEST_CONE, TEST_HIZ, TEST_ALL = 1, 2, 4, 7
 COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
-CMD_NV_MESHLETS, CMD_NV_TASKS32 = 0, 1
+CMD_NV_MESHLETS = 0
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
 
 # every symbol include/mcull.h declares
@@ -63,7 +63,7 @@ class CullParams(C.Structure):
     _fields_ = [("tests", C.c_uint32), ("compaction", C.c_uint32), ("hiz_view", C.c_uint32), ("cmd_form", C.c_uint32),
                 ("cmd_stride", C.c_uint32), ("cmd_offset", C.c_uint32), ("write_mask", C.c_uint32),
                 ("reserved", C.c_uint32), ("list", C.c_void_p), ("list_capacity", C.c_uint64),
-                ("commands", C.c_void_p)]
+                ("commands", C.c_void_p), ("total", C.c_void_p)]
 
 
 class CullResult(C.Structure):
@@ -237,10 +237,11 @@ class Context:
 
     # ---- cull + compact
     def cull(self, globals_, tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
-             cmd_stride=8, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None):
+             cmd_stride=8, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
+             total_ptr=None):
         g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
         p = CullParams(tests, compaction, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)), 0,
-                       list_ptr, list_capacity, commands_ptr)
+                       list_ptr, list_capacity, commands_ptr, total_ptr)
         r = CullResult()
         self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)

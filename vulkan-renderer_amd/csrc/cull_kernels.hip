@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
         task_count = next_first - my_first;
         first_task = my_first + (uint32_t)base;
     }
-    if (form == MCULL_CMD_NV_TASKS32) task_count = (task_count + 31u) / 32u;
+    (void)form;
     uint32_t *out = (uint32_t *)(commands + (size_t)i * stride + offset);
     out[0] = task_count;
     out[1] = first_task;

@@ -53,6 +53,7 @@ struct mcull_ctx {
 
     // cull scratch + outputs
     DevBuf mask, block_counts, inst_first, inst_count, total, list, commands;
+    uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
     // description of the last cull (for rebase / downloads / payloads)
     struct Last {
         bool valid = false;
@@ -489,9 +490,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     if (p.cmd_stride == 0) p.cmd_stride = 8;
     if (p.tests & ~MCULL_TEST_ALL) return fail(c, MCULL_E_INVALID, "unknown test bits 0x%x", p.tests);
     if (p.compaction > MCULL_COMPACT_BLOCK_ATOMIC) return fail(c, MCULL_E_INVALID, "unknown compaction %u", p.compaction);
-    if (p.cmd_form > MCULL_CMD_NV_TASKS32) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
-    if (p.cmd_form == MCULL_CMD_NV_TASKS32 && p.compaction != MCULL_COMPACT_ORDERED)
-        return fail(c, MCULL_E_INVALID, "TASKS32 commands need ordered compaction");
+    if (p.cmd_form != MCULL_CMD_NV_MESHLETS) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
     if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + 8u > p.cmd_stride)
         return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+8 <= stride");
     if ((p.tests & MCULL_TEST_HIZ) && (p.hiz_view >= MCULL_MAX_VIEWS || !c->hiz[p.hiz_view].built))
@@ -544,6 +543,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     const bool want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
     if (want_mask && (rc = ensure(c, c->mask, s.n_groups * 8))) return rc;
     if ((rc = ensure(c, c->total, 256))) return rc;
+    uint64_t *total = p.total ? p.total : (uint64_t *)c->total.p;
     mcull_visible *list = p.list;
     uint64_t capacity = p.list_capacity;
     if (!list) {
@@ -565,33 +565,34 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
 
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (s.n_groups == 0) {
-        HIPCHK(c, hipMemsetAsync(c->total.p, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
         if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
         HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
     } else if (p.compaction == MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, c->block_counts, (size_t)grid * 4))) return rc;
         if ((rc = ensure(c, c->inst_first, (c->n_instances + 1) * 4))) return rc;
         HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->block_counts.p, grid, c->stream));
         HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->block_counts.p, grid, list,
-                                        capacity, (uint32_t *)c->inst_first.p, (uint64_t *)c->total.p, c->stream));
+                                        capacity, (uint32_t *)c->inst_first.p, total, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
-                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
     } else {
         if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->total.p, 0, 256, c->stream));
+        HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
-        HIPCHK(c, mcull::launch_cull_atomic(s, v, list, capacity, (uint32_t *)c->inst_count.p, (uint64_t *)c->total.p,
+        HIPCHK(c, mcull::launch_cull_atomic(s, v, list, capacity, (uint32_t *)c->inst_count.p, total,
                                             p.write_mask ? (uint64_t *)c->mask.p : nullptr, grid,
                                             p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)c->total.p, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
 
     c->last.valid = true;
+    c->total_ptr = total;
     c->last.scene = s;
     c->last.uniform_count = uniform_count;
     c->last.compaction = p.compaction;
@@ -604,7 +605,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     if (result) {
         result->list = list;
         result->commands = commands;
-        result->total = (const uint64_t *)c->total.p;
+        result->total = (const uint64_t *)total;
         result->mask = c->last.have_mask ? (const uint64_t *)c->mask.p : nullptr;
         result->n_groups = s.n_groups;
         result->n_pairs = n_pairs;
@@ -621,7 +622,7 @@ int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t 
     HIPCHK(c, mcull::launch_emit_commands(c->last.scene, c->last.uniform_count,
                                           ordered ? (const uint32_t *)c->inst_first.p : nullptr,
                                           ordered ? nullptr : (const uint32_t *)c->inst_count.p,
-                                          (const uint64_t *)c->total.p, device_totals, rank, c->last.lay,
+                                          (const uint64_t *)c->total_ptr, device_totals, rank, c->last.lay,
                                           c->last.commands, c->stream));
     return MCULL_OK;
 }
@@ -646,7 +647,7 @@ int mcull_download_count(mcull_ctx *c, uint64_t *total) {
     if (!c || !total) return MCULL_E_INVALID;
     if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(total, c->total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(total, c->total_ptr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCULL_OK;
 }
