@@ -209,7 +209,7 @@ def cpu_baseline(cone, sphere, xf, off, cnt, g, tests, n_inst, per):
     rng = (off[:sample], cnt[:sample])
     O.cull_scene(view, t[:1024], cone_axis_w=c, centre_radius=s, ranges=(off[:1024], cnt[:1024]), tests=tests, threads=threads)
     reps, t_used = 0, 0.0
-    while t_used < 10.0 and reps < 20:
+    while t_used < 10.0 and reps < 400:
         t0 = time.perf_counter()
         r = O.cull_scene(view, t, cone_axis_w=c, centre_radius=s, ranges=rng, tests=tests, threads=threads)
         t_used += time.perf_counter() - t0

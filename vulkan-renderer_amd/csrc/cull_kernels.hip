@@ -10,9 +10,9 @@
 // shaders/shader.task:37-101.
 //
 // Compaction strategies:
-//   ordered      cull_mask_kernel  -> one 64-bit ballot word per group + one count per workgroup
-//                compact_kernel    -> workgroup base = sum of lower workgroups' counts, block scan,
-//                                     scatter; list sorted by (drawID, meshletID)
+//   ordered      cull_mask_kernel  -> one 64-bit ballot word per group + one count per 256-group tile
+//                scan_tiles_kernel -> exclusive prefix of the tile counts (+ the total)
+//                compact_kernel    -> per-tile block scan + scatter; list sorted by (drawID, meshletID)
 //                emit_commands_kernel -> {taskCount, firstTask} per instance
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
 //                workgroup step), list order unspecified.
@@ -22,6 +22,7 @@ namespace mcull {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kTileGroups = 256;  // groups per workgroup tile = 16384 meshlet-instances
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax * bx + ay * by) + az * bz;
@@ -52,6 +53,7 @@ struct Xform {
 };
 
 // shader.task:85-101 for one pair.  `a` = {axis.xyz, coneW}, `c` = {centre.xyz, radius}.
+template <uint32_t TESTS>
 __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float4 a, float4 c) {
     // world-space centre (shader.task:91), axis (:95), radius (:99)
     const float wx = ((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x;
@@ -60,14 +62,14 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
     const float r = c.w * sqrtf(dot3(m.c0.x, m.c0.y, m.c0.z, m.c0.x, m.c0.y, m.c0.z));
 
     bool culled = false;
-    if (v.tests & MCULL_TEST_FRUSTUM) {  // frustumCull, shader.task:43-56
+    if (TESTS & MCULL_TEST_FRUSTUM) {  // frustumCull, shader.task:43-56
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             const float d = (dot3(v.frustum[i][0], v.frustum[i][1], v.frustum[i][2], wx, wy, wz) + v.frustum[i][3]) + r;
             culled |= d < 0.0f;
         }
     }
-    if ((v.tests & MCULL_TEST_HIZ) && !culled) {  // occlusionCull, shader.task:58-77
+    if ((TESTS & MCULL_TEST_HIZ) && !culled) {  // occlusionCull, shader.task:58-77
         const float cx = ((v.vp[0] * wx + v.vp[4] * wy) + v.vp[8] * wz) + v.vp[12];
         const float cy = ((v.vp[1] * wx + v.vp[5] * wy) + v.vp[9] * wz) + v.vp[13];
         const float cz = ((v.vp[2] * wx + v.vp[6] * wy) + v.vp[10] * wz) + v.vp[14];
@@ -84,7 +86,7 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
         const float d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];
         culled = nz < d - 0.05f;
     }
-    if ((v.tests & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
+    if ((TESTS & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
         float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
         float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
         float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
@@ -98,31 +100,27 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
     return !culled;
 }
 
-// Which instance / local group / meshlet range a group belongs to.  All values are wave-uniform.
+// Which instance / meshlet range a group belongs to.  All values are wave-uniform.
+// Scenes with per-instance ranges carry one precomputed 16-byte record per group
+// {instance, first meshlet, meshlets in this group (<= 64), local group index}; scenes where
+// every instance draws [0, meshletCount) (the reference's case, shader.task:85) derive it.
 struct GroupInfo {
-    uint32_t inst, first_meshlet, count;  // count = meshlets of this group that exist (<= 64)
-    uint32_t local_group;
+    uint32_t inst, first_meshlet, count, local_group;
 };
 
-__device__ __forceinline__ GroupInfo group_lookup(uint32_t g, const uint2 *__restrict__ ranges,
-                                                  const uint32_t *__restrict__ group_base,
-                                                  const uint32_t *__restrict__ group_inst,
+__device__ __forceinline__ GroupInfo group_lookup(uint32_t g, const uint4 *__restrict__ group_rec,
                                                   uint32_t groups_per_instance, uint32_t uniform_count) {
     GroupInfo gi;
-    uint32_t moff, mcnt;
-    if (group_inst) {
-        gi.inst = group_inst[g];
-        gi.local_group = g - group_base[gi.inst];
-        const uint2 r = ranges[gi.inst];
-        moff = r.x; mcnt = r.y;
+    if (group_rec) {
+        const uint4 r = group_rec[g];
+        gi.inst = r.x; gi.first_meshlet = r.y; gi.count = r.z; gi.local_group = r.w;
     } else {
         gi.inst = g / groups_per_instance;
         gi.local_group = g - gi.inst * groups_per_instance;
-        moff = 0; mcnt = uniform_count;
+        gi.first_meshlet = gi.local_group * 64u;
+        const uint32_t left = uniform_count - gi.first_meshlet;
+        gi.count = left < 64u ? left : 64u;
     }
-    gi.first_meshlet = moff + gi.local_group * 64u;
-    const uint32_t left = mcnt - gi.local_group * 64u;
-    gi.count = left < 64u ? left : 64u;
     return gi;
 }
 
@@ -134,34 +132,56 @@ __device__ __forceinline__ Xform load_xform(const float4 *__restrict__ transform
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered, pass 1: visibility ballots
+// ordered, pass 1: visibility ballots.  One workgroup per tile of kTileGroups groups; wave w takes
+// groups tile*256 + w, +4, +8 ...  The bounds of the next group are requested before the current
+// group is evaluated, so every wave keeps two 2-KiB requests in flight.
+template <uint32_t TESTS>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
-    const float4 *__restrict__ transforms, const uint2 *__restrict__ ranges,
-    const uint32_t *__restrict__ group_base, const uint32_t *__restrict__ group_inst,
-    uint32_t groups_per_instance, uint32_t n_groups, uint32_t groups_per_block, ViewConst v,
-    uint64_t *__restrict__ mask, uint32_t *__restrict__ block_counts) {
+    const float4 *__restrict__ transforms, const uint4 *__restrict__ group_rec,
+    uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
+    uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts) {
     __shared__ uint32_t s_count[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t g_begin = blockIdx.x * groups_per_block;
-    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
+    const uint32_t g_begin = blockIdx.x * kTileGroups;
+    const uint32_t g_end = min(g_begin + kTileGroups, n_groups);
     uint32_t count = 0;
-    for (uint32_t g = g_begin + wave; g < g_end; g += kWaves) {
-        const GroupInfo gi = group_lookup(g, ranges, group_base, group_inst, groups_per_instance, v.uniform_count);
-        const Xform m = load_xform(transforms, gi.inst);
-        bool vis = false;
+
+    uint32_t g = g_begin + wave;
+    GroupInfo gi = {0, 0, 0, 0};
+    Xform m = {};
+    float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+    if (g < g_end) {
+        gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
+        m = load_xform(transforms, gi.inst);
         if (lane < gi.count) {
-            const uint32_t id = gi.first_meshlet + lane;
-            vis = pair_visible(v, m, cone_axis_w[id], centre_radius[id]);
+            a = cone_axis_w[gi.first_meshlet + lane];
+            c = centre_radius[gi.first_meshlet + lane];
         }
+    }
+    while (g < g_end) {
+        const uint32_t gn = g + kWaves;
+        GroupInfo gin = {0, 0, 0, 0};
+        Xform mn = {};
+        float4 an = make_float4(0, 0, 0, 0), cn = make_float4(0, 0, 0, 0);
+        if (gn < g_end) {
+            gin = group_lookup(gn, group_rec, groups_per_instance, v.uniform_count);
+            mn = load_xform(transforms, gin.inst);
+            if (lane < gin.count) {
+                an = cone_axis_w[gin.first_meshlet + lane];
+                cn = centre_radius[gin.first_meshlet + lane];
+            }
+        }
+        const bool vis = (lane < gi.count) && pair_visible<TESTS>(v, m, a, c);
         const uint64_t ballot = __ballot(vis);
         if (lane == 0) mask[g] = ballot;
         count += (uint32_t)__popcll(ballot);
+        g = gn; gi = gin; m = mn; a = an; c = cn;
     }
     if (lane == 0) s_count[wave] = count;
     __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
 }
 
 // exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
@@ -189,77 +209,92 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered, pass 2: scatter.  Same group partition as pass 1.
+// ordered, between the passes: exclusive prefix of the per-tile visible counts (one workgroup).
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
+                                                                unsigned long long *__restrict__ tile_base,
+                                                                unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long s_wave[kScanBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += kScanBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long x = i < n_tiles ? tile_counts[i] : 0ull;
+        unsigned long long incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned long long wave_base = 0, chunk_total = 0;
+#pragma unroll
+        for (int w = 0; w < kScanBlock / 64; w++) {
+            const unsigned long long t = s_wave[w];
+            if ((uint32_t)w < wave) wave_base += t;
+            chunk_total += t;
+        }
+        if (i < n_tiles) tile_base[i] = carry + wave_base + incl - x;
+        carry += chunk_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered, pass 2: scatter.  One workgroup per tile, one group per thread for the scan, then one
+// group per wave-iteration for the stores (lane l owns bit l; slots are contiguous per group).
 __global__ __launch_bounds__(kBlock) void compact_kernel(
-    const uint64_t *__restrict__ mask, const uint32_t *__restrict__ block_counts,
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ group_base,
-    const uint32_t *__restrict__ group_inst, uint32_t groups_per_instance,
-    uint32_t n_groups, uint32_t groups_per_block, mcull_visible *__restrict__ list, uint64_t capacity,
-    uint32_t *__restrict__ inst_first, uint64_t *__restrict__ total) {
+    const uint64_t *__restrict__ mask, const unsigned long long *__restrict__ tile_base,
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups,
+    mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first) {
     __shared__ uint64_t s_word[kBlock];
     __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
     __shared__ uint32_t s_wave[kWaves];
-    __shared__ unsigned long long s_sum[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // base of this workgroup = sum of the visible counts of all lower workgroups
-    unsigned long long part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += block_counts[j];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    if (lane == 0) s_sum[wave] = part;
-    __syncthreads();
-    unsigned long long running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + block_counts[blockIdx.x];
-
-    const uint32_t g_begin = blockIdx.x * groups_per_block;
-    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
-    for (uint32_t tile = g_begin; tile < g_end; tile += kBlock) {
-        const uint32_t g = tile + threadIdx.x;
-        uint64_t word = 0;
-        uint32_t inst = 0, first = 0, is_first_group = 0;
-        if (g < g_end) {
-            word = mask[g];
-            uint32_t lg, moff;
-            if (group_inst) {
-                inst = group_inst[g];
-                lg = g - group_base[inst];
-                moff = ranges[inst].x;
-            } else {
-                inst = g / groups_per_instance;
-                lg = g - inst * groups_per_instance;
-                moff = 0;
-            }
-            first = moff + lg * 64u;
+    const unsigned long long running = tile_base[blockIdx.x];
+    const uint32_t tile = blockIdx.x * kTileGroups;
+    const uint32_t g_end = min(tile + kTileGroups, n_groups);
+    const uint32_t g = tile + threadIdx.x;
+    uint64_t word = 0;
+    uint32_t inst = 0, first = 0, is_first_group = 0;
+    if (g < g_end) {
+        word = mask[g];
+        if (group_rec) {
+            const uint4 r = group_rec[g];
+            inst = r.x; first = r.y; is_first_group = (r.w == 0u);
+        } else {
+            inst = g / groups_per_instance;
+            const uint32_t lg = g - inst * groups_per_instance;
+            first = lg * 64u;
             is_first_group = (lg == 0u);
         }
-        uint32_t tile_total;
-        const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(word), s_wave, &tile_total);
-        s_word[threadIdx.x] = word;
-        s_off[threadIdx.x] = excl;
-        s_inst[threadIdx.x] = inst;
-        s_first[threadIdx.x] = first;
-        // firstTask of an instance = list offset of its first group (exclusive scan in instance order)
-        if (g < g_end && is_first_group) inst_first[inst] = (uint32_t)(running + excl);
-        __syncthreads();
-        const uint32_t n_tile = min((uint32_t)kBlock, g_end - tile);
-        for (uint32_t j = wave; j < n_tile; j += kWaves) {
-            const uint64_t w = s_word[j];
-            if (w == 0) continue;
-            const unsigned long long base = running + s_off[j];
-            if ((w >> lane) & 1ull) {
-                const unsigned long long slot = base + (unsigned long long)__popcll(w & ((1ull << lane) - 1ull));
-                if (slot < capacity) {
-                    mcull_visible e;
-                    e.drawID = s_inst[j];
-                    e.meshletID = s_first[j] + lane;
-                    list[slot] = e;
-                }
+    }
+    uint32_t tile_total;
+    const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(word), s_wave, &tile_total);
+    s_word[threadIdx.x] = word;
+    s_off[threadIdx.x] = excl;
+    s_inst[threadIdx.x] = inst;
+    s_first[threadIdx.x] = first;
+    // firstTask of an instance = list offset of its first group (exclusive scan in instance order)
+    if (g < g_end && is_first_group) inst_first[inst] = (uint32_t)(running + excl);
+    __syncthreads();
+    const uint32_t n_tile = g_end - tile;
+    for (uint32_t j = wave; j < n_tile; j += kWaves) {
+        const uint64_t w = s_word[j];
+        if (w == 0) continue;
+        const unsigned long long base = running + s_off[j];
+        if ((w >> lane) & 1ull) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(w & ((1ull << lane) - 1ull));
+            if (slot < capacity) {
+                mcull_visible e;
+                e.drawID = s_inst[j];
+                e.meshletID = s_first[j] + lane;
+                list[slot] = e;
             }
         }
-        running += tile_total;
-        __syncthreads();
     }
 }
 
@@ -302,33 +337,31 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
 // single-pass compaction with atomics.  BLOCK = false: one returning atomic per wavefront
 // (ballot -> popcount -> lane 0 atomicAdd -> readfirstlane broadcast -> mbcnt scatter);
 // BLOCK = true: the four waves of a workgroup share one atomic per step.
-template <bool BLOCK>
+template <uint32_t TESTS, bool BLOCK>
 __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
-    const float4 *__restrict__ transforms, const uint2 *__restrict__ ranges,
-    const uint32_t *__restrict__ group_base, const uint32_t *__restrict__ group_inst,
-    uint32_t groups_per_instance, uint32_t n_groups, uint32_t groups_per_block, ViewConst v,
+    const float4 *__restrict__ transforms, const uint4 *__restrict__ group_rec,
+    uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
     mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_count,
     unsigned long long *__restrict__ total, uint64_t *__restrict__ mask) {
     __shared__ uint32_t s_pop[2][kWaves];
     __shared__ unsigned long long s_base[2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t g_begin = blockIdx.x * groups_per_block;
-    const uint32_t g_end = min(g_begin + groups_per_block, n_groups);
-    const uint32_t steps = (g_end > g_begin) ? (g_end - g_begin + kWaves - 1) / kWaves : 0;
+    const uint32_t g_begin = blockIdx.x * kTileGroups;
+    const uint32_t g_end = min(g_begin + kTileGroups, n_groups);
+    const uint32_t steps = (g_end - g_begin + kWaves - 1) / kWaves;
     for (uint32_t it = 0; it < steps; it++) {
         const uint32_t g = g_begin + it * kWaves + wave;
         const bool active = g < g_end;
         bool vis = false;
-        GroupInfo gi;
-        gi.inst = 0; gi.first_meshlet = 0; gi.count = 0; gi.local_group = 0;
+        GroupInfo gi = {0, 0, 0, 0};
         if (active) {
-            gi = group_lookup(g, ranges, group_base, group_inst, groups_per_instance, v.uniform_count);
+            gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
             const Xform m = load_xform(transforms, gi.inst);
             if (lane < gi.count) {
                 const uint32_t id = gi.first_meshlet + lane;
-                vis = pair_visible(v, m, cone_axis_w[id], centre_radius[id]);
+                vis = pair_visible<TESTS>(v, m, cone_axis_w[id], centre_radius[id]);
             }
         }
         const uint64_t ballot = __ballot(vis);
@@ -369,13 +402,19 @@ __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void fill_group_inst_kernel(const uint32_t *__restrict__ group_base,
-                                                                 uint32_t n_instances,
-                                                                 uint32_t *__restrict__ group_inst) {
+// one 16-byte record per group for scenes with per-instance ranges
+__global__ __launch_bounds__(kBlock) void fill_group_rec_kernel(const uint2 *__restrict__ ranges,
+                                                                const uint32_t *__restrict__ group_base,
+                                                                uint32_t n_instances, uint4 *__restrict__ group_rec) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_instances) return;
     const uint32_t b = group_base[i], e = group_base[i + 1];
-    for (uint32_t g = b; g < e; g++) group_inst[g] = i;
+    const uint2 r = ranges[i];
+    for (uint32_t g = b; g < e; g++) {
+        const uint32_t lg = g - b;
+        const uint32_t left = r.y - lg * 64u;
+        group_rec[g] = make_uint4(i, r.x + lg * 64u, left < 64u ? left : 64u, lg);
+    }
 }
 
 // The literal payload of every 32-wide task workgroup (shader.task:28-35, :103-118) rebuilt from
@@ -403,35 +442,41 @@ __global__ __launch_bounds__(kBlock) void task_payload_kernel(const uint64_t *__
 }
 
 // ------------------------------------------------------------------------------------------------
-uint32_t cull_grid_for(uint64_t n_groups, int cu_count) {
-    // persistent-style grid: up to 8 workgroups of 4 waves per CU, each walking a contiguous
-    // range of groups; never more workgroups than there are 4-group steps.
-    uint64_t want = (n_groups + kWaves - 1) / kWaves;
-    uint64_t cap = (uint64_t)cu_count * 8;
-    uint64_t grid = want < cap ? want : cap;
-    return (uint32_t)(grid ? grid : 1);
-}
+uint32_t tile_count_for(uint64_t n_groups) { return (uint32_t)((n_groups + kTileGroups - 1) / kTileGroups); }
 
-static inline uint32_t groups_per_block_for(uint64_t n_groups, uint32_t grid) {
-    return (uint32_t)((n_groups + grid - 1) / grid);
-}
+#define MCULL_DISPATCH_TESTS(tests, CALL)                                        \
+    switch ((tests) & 7u) {                                                      \
+        case 0: { constexpr uint32_t T = 0; CALL; break; }                       \
+        case 1: { constexpr uint32_t T = 1; CALL; break; }                       \
+        case 2: { constexpr uint32_t T = 2; CALL; break; }                       \
+        case 3: { constexpr uint32_t T = 3; CALL; break; }                       \
+        case 4: { constexpr uint32_t T = 4; CALL; break; }                       \
+        case 5: { constexpr uint32_t T = 5; CALL; break; }                       \
+        case 6: { constexpr uint32_t T = 6; CALL; break; }                       \
+        default: { constexpr uint32_t T = 7; CALL; break; }                      \
+    }
 
-hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *block_counts,
-                            uint32_t grid, hipStream_t st) {
-    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
-    hipLaunchKernelGGL(cull_mask_kernel, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, s.transforms,
-                       s.ranges, s.group_base, s.group_inst, s.groups_per_instance, (uint32_t)s.n_groups, gpb, v, mask,
-                       block_counts);
+hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
+                            hipStream_t st) {
+    const uint32_t grid = tile_count_for(s.n_groups);
+    MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL(cull_mask_kernel<T>, dim3(grid), dim3(kBlock), 0, st,
+                                                     s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts));
     return hipGetLastError();
 }
 
-hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *block_counts, uint32_t grid,
-                          mcull_visible *list, uint64_t capacity, uint32_t *inst_first, uint64_t *total,
-                          hipStream_t st) {
-    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kBlock), 0, st, mask, block_counts, s.ranges, s.group_base,
-                       s.group_inst, s.groups_per_instance, (uint32_t)s.n_groups, gpb, list, capacity, inst_first,
-                       total);
+hipError_t launch_scan_tiles(const uint32_t *tile_counts, uint32_t n_tiles, uint64_t *tile_base, uint64_t *total,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanBlock), 0, st, tile_counts, n_tiles,
+                       (unsigned long long *)tile_base, (unsigned long long *)total);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint64_t *tile_base, mcull_visible *list,
+                          uint64_t capacity, uint32_t *inst_first, hipStream_t st) {
+    const uint32_t grid = tile_count_for(s.n_groups);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kBlock), 0, st, mask, (const unsigned long long *)tile_base,
+                       s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first);
     return hipGetLastError();
 }
 
@@ -447,25 +492,27 @@ hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const
 }
 
 hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
-                              uint32_t *inst_count, uint64_t *total, uint64_t *mask, uint32_t grid, bool block_mode,
-                              hipStream_t st) {
-    const uint32_t gpb = groups_per_block_for(s.n_groups, grid);
-    if (block_mode)
-        hipLaunchKernelGGL(cull_atomic_kernel<true>, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
-                           s.transforms, s.ranges, s.group_base, s.group_inst, s.groups_per_instance,
-                           (uint32_t)s.n_groups, gpb, v, list, capacity, inst_count, (unsigned long long *)total, mask);
-    else
-        hipLaunchKernelGGL(cull_atomic_kernel<false>, dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
-                           s.transforms, s.ranges, s.group_base, s.group_inst, s.groups_per_instance,
-                           (uint32_t)s.n_groups, gpb, v, list, capacity, inst_count, (unsigned long long *)total, mask);
+                              uint32_t *inst_count, uint64_t *total, uint64_t *mask, bool block_mode, hipStream_t st) {
+    const uint32_t grid = tile_count_for(s.n_groups);
+    if (block_mode) {
+        MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_atomic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st,
+                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+                                                         s.groups_per_instance, (uint32_t)s.n_groups, v, list, capacity,
+                                                         inst_count, (unsigned long long *)total, mask));
+    } else {
+        MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_atomic_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st,
+                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+                                                         s.groups_per_instance, (uint32_t)s.n_groups, v, list, capacity,
+                                                         inst_count, (unsigned long long *)total, mask));
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_fill_group_inst(const uint32_t *group_base, uint32_t n_instances, uint32_t *group_inst,
-                                  hipStream_t st) {
+hipError_t launch_fill_group_rec(const uint2 *ranges, const uint32_t *group_base, uint32_t n_instances,
+                                 uint4 *group_rec, hipStream_t st) {
     if (n_instances == 0) return hipSuccess;
-    hipLaunchKernelGGL(fill_group_inst_kernel, dim3((n_instances + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                       group_base, n_instances, group_inst);
+    hipLaunchKernelGGL(fill_group_rec_kernel, dim3((n_instances + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ranges,
+                       group_base, n_instances, group_rec);
     return hipGetLastError();
 }
 

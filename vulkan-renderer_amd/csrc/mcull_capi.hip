@@ -41,7 +41,7 @@ struct mcull_ctx {
     std::string err;
 
     // scene
-    DevBuf aos, cone, sphere, vertices, mdata, transforms, ranges, group_base, group_inst;
+    DevBuf aos, cone, sphere, vertices, mdata, transforms, ranges, group_base, group_rec;
     uint64_t n_meshlets = 0, n_vertices = 0, n_words = 0, n_instances = 0;
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
     uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
@@ -52,7 +52,7 @@ struct mcull_ctx {
     bool hiz_single_pass = true;
 
     // cull scratch + outputs
-    DevBuf mask, block_counts, inst_first, inst_count, total, list, commands;
+    DevBuf mask, tile_counts, tile_base, inst_first, inst_count, total, list, commands;
     uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
     // description of the last cull (for rebase / downloads / payloads)
     struct Last {
@@ -220,7 +220,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->ranges,
-                      &c->group_base, &c->group_inst, &c->depth_staging, &c->hiz_counter, &c->mask, &c->block_counts,
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->mask, &c->tile_counts, &c->tile_base,
                       &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands};
     for (DevBuf *b : bufs) release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
@@ -388,11 +388,11 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
     int rc;
     if ((rc = ensure(c, c->ranges, rg.size() * 4))) return rc;
     if ((rc = ensure(c, c->group_base, base.size() * 4))) return rc;
-    if ((rc = ensure(c, c->group_inst, groups * 4))) return rc;
+    if ((rc = ensure(c, c->group_rec, groups * 16))) return rc;
     if ((rc = copy_in(c, c->ranges.p, rg.data(), rg.size() * 4, MCULL_MEM_HOST))) return rc;
     if ((rc = copy_in(c, c->group_base.p, base.data(), base.size() * 4, MCULL_MEM_HOST))) return rc;
-    HIPCHK(c, mcull::launch_fill_group_inst((const uint32_t *)c->group_base.p, (uint32_t)n_instances,
-                                            (uint32_t *)c->group_inst.p, c->stream));
+    HIPCHK(c, mcull::launch_fill_group_rec((const uint2 *)c->ranges.p, (const uint32_t *)c->group_base.p,
+                                           (uint32_t)n_instances, (uint4 *)c->group_rec.p, c->stream));
     c->have_ranges = true;
     c->ranged_groups = groups;
     c->ranged_pairs = pairs;
@@ -510,8 +510,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
                         (unsigned long long)c->ranged_instances, (unsigned long long)c->n_instances);
         if (c->ranged_max_end > c->n_meshlets) return fail(c, MCULL_E_INVALID, "an instance range exceeds the meshlet array");
         s.ranges = (const uint2 *)c->ranges.p;
-        s.group_base = (const uint32_t *)c->group_base.p;
-        s.group_inst = (const uint32_t *)c->group_inst.p;
+        s.group_rec = (const uint4 *)c->group_rec.p;
         s.groups_per_instance = 0;
         s.n_groups = c->ranged_groups;
         n_pairs = c->ranged_pairs;
@@ -560,7 +559,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         if (fresh) HIPCHK(c, hipMemsetAsync(c->commands.p, 0, c->commands.cap, c->stream));
         commands = c->commands.p;
     }
-    const uint32_t grid = mcull::cull_grid_for(s.n_groups, c->cu_count);
+    const uint32_t n_tiles = mcull::tile_count_for(s.n_groups);
     const mcull::CmdLayout lay{p.cmd_stride, p.cmd_offset, p.cmd_form};
 
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -571,11 +570,14 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
                                               (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
     } else if (p.compaction == MCULL_COMPACT_ORDERED) {
-        if ((rc = ensure(c, c->block_counts, (size_t)grid * 4))) return rc;
+        if ((rc = ensure(c, c->tile_counts, (size_t)n_tiles * 4))) return rc;
+        if ((rc = ensure(c, c->tile_base, (size_t)n_tiles * 8))) return rc;
         if ((rc = ensure(c, c->inst_first, (c->n_instances + 1) * 4))) return rc;
-        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->block_counts.p, grid, c->stream));
-        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->block_counts.p, grid, list,
-                                        capacity, (uint32_t *)c->inst_first.p, total, c->stream));
+        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->tile_counts.p, c->stream));
+        HIPCHK(c, mcull::launch_scan_tiles((const uint32_t *)c->tile_counts.p, n_tiles, (uint64_t *)c->tile_base.p, total,
+                                           c->stream));
+        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint64_t *)c->tile_base.p, list, capacity,
+                                        (uint32_t *)c->inst_first.p, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
                                               (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
     } else {
@@ -583,7 +585,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
         HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
         HIPCHK(c, mcull::launch_cull_atomic(s, v, list, capacity, (uint32_t *)c->inst_count.p, total,
-                                            p.write_mask ? (uint64_t *)c->mask.p : nullptr, grid,
+                                            p.write_mask ? (uint64_t *)c->mask.p : nullptr,
                                             p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
                                               (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
