@@ -1,0 +1,181 @@
+// Access-pattern experiments for the cull kernel (not part of the product): how fast can the two
+// SoA bounds streams be consumed under different group->wave assignments?  Build + run:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I. tools/bench_patterns.hip -o tools/bench_patterns
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "../vulkan-renderer_amd/csrc/cull_kernels.hip"
+
+using namespace mcull;
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4 *p) {
+    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// B: persistent, globally strided: iteration k of block b, wave w -> group (k*P + b)*4 + w
+template <uint32_t TESTS, int DEPTH>
+__global__ __launch_bounds__(kBlock) void cull_strided_kernel(const float4 *__restrict__ cone_axis_w,
+                                                              const float4 *__restrict__ centre_radius,
+                                                              const float4 *__restrict__ transforms,
+                                                              const uint4 *__restrict__ group_rec,
+                                                              uint32_t groups_per_instance, uint32_t n_groups,
+                                                              ViewConst v, uint64_t *__restrict__ mask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t stride = gridDim.x * kWaves;
+    uint32_t g = blockIdx.x * kWaves + wave;
+    GroupInfo gi = {0, 0, 0, 0};
+    Xform m = {};
+    float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+    if (g < n_groups) {
+        gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
+        m = load_xform(transforms, gi.inst);
+        if (lane < gi.count) { a = cone_axis_w[gi.first_meshlet + lane]; c = centre_radius[gi.first_meshlet + lane]; }
+    }
+    while (g < n_groups) {
+        const uint32_t gn = g + stride;
+        GroupInfo gin = {0, 0, 0, 0};
+        Xform mn = {};
+        float4 an = make_float4(0, 0, 0, 0), cn = make_float4(0, 0, 0, 0);
+        if (gn < n_groups) {
+            gin = group_lookup(gn, group_rec, groups_per_instance, v.uniform_count);
+            mn = load_xform(transforms, gin.inst);
+            if (lane < gin.count) { an = cone_axis_w[gin.first_meshlet + lane]; cn = centre_radius[gin.first_meshlet + lane]; }
+        }
+        const bool vis = (lane < gi.count) && pair_visible<TESTS>(v, m, xform_scale(m.c0), a, c);
+        const uint64_t ballot = __ballot(vis);
+        if (lane == 0) mask[g] = ballot;
+        g = gn; gi = gin; m = mn; a = an; c = cn;
+    }
+}
+
+// D: read floor: same two streams, trivial arithmetic (sum of .w), strided or tile walk
+template <bool STRIDED, int UNROLL, bool NT>
+__global__ __launch_bounds__(kBlock) void read_floor_kernel(const float4 *__restrict__ cone_axis_w,
+                                                            const float4 *__restrict__ centre_radius, uint32_t n_groups,
+                                                            uint64_t *__restrict__ mask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t g, g_end, step;
+    if (STRIDED) { g = blockIdx.x * kWaves + wave; g_end = n_groups; step = gridDim.x * kWaves; }
+    else { g = blockIdx.x * kTileGroups + wave; g_end = min(blockIdx.x * kTileGroups + kTileGroups, n_groups); step = kWaves; }
+    for (; g < g_end; g += step * UNROLL) {
+        float4 a[UNROLL], c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t gg = min(g + u * step, g_end - 1);
+            if (NT) { a[u] = nt_load(&cone_axis_w[(size_t)gg * 64 + lane]); c[u] = nt_load(&centre_radius[(size_t)gg * 64 + lane]); }
+            else { a[u] = cone_axis_w[(size_t)gg * 64 + lane]; c[u] = centre_radius[(size_t)gg * 64 + lane]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint64_t ballot = __ballot(a[u].w + c[u].w > 0.6f);
+            if (lane == 0 && g + u * step < g_end) mask[g + u * step] = ballot;
+        }
+    }
+}
+
+int main(int argc, char **argv) {
+    const uint32_t n_inst = 781250, per = 128;
+    const uint64_t n = (uint64_t)n_inst * per;
+    const uint32_t n_groups = n_inst * 2;
+    float4 *cone, *sphere, *xf; uint4 *rec; uint64_t *mask; uint32_t *tc;
+    CK(hipMalloc(&cone, n * 16)); CK(hipMalloc(&sphere, n * 16)); CK(hipMalloc(&xf, (size_t)n_inst * 64));
+    CK(hipMalloc(&rec, (size_t)n_groups * 16)); CK(hipMalloc(&mask, (size_t)n_groups * 8)); CK(hipMalloc(&tc, 1 << 20));
+    float *scale; CK(hipMalloc(&scale, (size_t)n_inst * 4));
+    {
+        std::vector<float4> h(1 << 22), h2(1 << 22);
+        srand(1);
+        auto U = [] { return rand() / (float)RAND_MAX; };
+        for (auto &q : h) {  // unit axis + coneW
+            float x = U() - 0.5f, y = U() - 0.5f, z = U() - 0.5f, l = sqrtf(x * x + y * y + z * z) + 1e-9f;
+            q = make_float4(x / l, y / l, z / l, U() < 0.1f ? 1.0f : U());
+        }
+        for (auto &q : h2) q = make_float4(U(), U(), U(), 0.01f + 0.04f * U());
+        for (uint64_t o = 0; o < n; o += h.size()) {
+            uint64_t k = std::min<uint64_t>(h.size(), n - o);
+            CK(hipMemcpy(cone + o, h.data(), k * 16, hipMemcpyHostToDevice));
+            CK(hipMemcpy(sphere + o, h2.data(), k * 16, hipMemcpyHostToDevice));
+        }
+        std::vector<float> t((size_t)n_inst * 16, 0.f), sc(n_inst, 1.0f);
+        for (uint32_t i = 0; i < n_inst; i++) {
+            float qw = U() - 0.5f, qx = U() - 0.5f, qy = U() - 0.5f, qz = U() - 0.5f, l = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw /= l; qx /= l; qy /= l; qz /= l;
+            float *m = &t[16 * i];
+            m[0] = 1 - 2 * (qy * qy + qz * qz); m[4] = 2 * (qx * qy - qz * qw); m[8] = 2 * (qx * qz + qy * qw);
+            m[1] = 2 * (qx * qy + qz * qw); m[5] = 1 - 2 * (qx * qx + qz * qz); m[9] = 2 * (qy * qz - qx * qw);
+            m[2] = 2 * (qx * qz - qy * qw); m[6] = 2 * (qy * qz + qx * qw); m[10] = 1 - 2 * (qx * qx + qy * qy);
+            for (int k = 0; k < 3; k++) m[12 + k] = (U() - 0.5f) * 100.f;
+            m[15] = 1.f;
+            sc[i] = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        }
+        CK(hipMemcpy(xf, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint4> r(n_groups);
+        for (uint32_t g = 0; g < n_groups; g++) r[g] = make_uint4(g / 2, (g / 2) * per + (g & 1) * 64, 64, g & 1);
+        CK(hipMemcpy(rec, r.data(), r.size() * 16, hipMemcpyHostToDevice));
+    }
+    ViewConst v{};
+    {   // the benchmark camera: eye (51, 54.4, 40.8) looking at the origin, fov 45, aspect 16:9
+        const float ex = 51.f, ey = 54.4f, ez = 40.8f, el = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float f[3] = {-ex / el, -ey / el, -ez / el};
+        float sx = f[1], sy = -f[0], sl = sqrtf(sx * sx + sy * sy); sx /= sl; sy /= sl;      // s = f x (0,0,1)
+        const float s3[3] = {sx, sy, 0.f};
+        const float u[3] = {s3[1] * f[2] - s3[2] * f[1], s3[2] * f[0] - s3[0] * f[2], s3[0] * f[1] - s3[1] * f[0]};
+        const float th = tanf(0.3926991f), ta = th * 16.f / 9.f;
+        auto plane = [&](int i, float nx, float ny, float nz) {
+            const float l = sqrtf(nx * nx + ny * ny + nz * nz); nx /= l; ny /= l; nz /= l;
+            v.frustum[i][0] = nx; v.frustum[i][1] = ny; v.frustum[i][2] = nz; v.frustum[i][3] = -(nx * ex + ny * ey + nz * ez);
+        };
+        plane(0, f[0] * ta + s3[0], f[1] * ta + s3[1], f[2] * ta + s3[2]);
+        plane(1, f[0] * ta - s3[0], f[1] * ta - s3[1], f[2] * ta - s3[2]);
+        plane(2, f[0] * th + u[0], f[1] * th + u[1], f[2] * th + u[2]);
+        plane(3, f[0] * th - u[0], f[1] * th - u[1], f[2] * th - u[2]);
+        plane(4, f[0], f[1], f[2]);
+        v.cam[0] = ex; v.cam[1] = ey; v.cam[2] = ez; v.tests = 3;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char *name, auto &&launch) {
+        for (int i = 0; i < 3; i++) launch();
+        CK(hipDeviceSynchronize());
+        float best = 1e9f, sum = 0;
+        for (int r = 0; r < 10; r++) {
+            CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms); sum += ms;
+        }
+        CK(hipGetLastError());
+        printf("%-44s avg %.1f us  best %.1f us  (%.2f TB/s of bounds)\n", name, sum * 100, best * 1000, n * 32 / (sum / 10 * 1e-3) / 1e12);
+    };
+    const uint32_t tiles = (n_groups + 255) / 256;
+    uint32_t *sc; CK(hipMalloc(&sc, 1 << 16)); CK(hipMemset(tc, 0, 1 << 20)); CK(hipMemset(sc, 0, 1 << 16));
+#define PRODUCT(NG, NT) timeit("product cull_mask_kernel<3," #NG "," #NT ">", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, NG, NT>), dim3((n_groups + 4 * NG - 1) / (4 * NG)), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc); });
+    PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(3, true) PRODUCT(4, false) PRODUCT(4, true)
+    {
+        std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
+        uint64_t vis = 0; for (auto w : hm) vis += __builtin_popcountll(w);
+        printf("visible fraction %.3f\n", (double)vis / n);
+    }
+    for (int bpc : {6, 12}) {
+        char nm[64]; snprintf(nm, sizeof nm, "B strided persistent, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL((cull_strided_kernel<3, 1>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, xf, rec, 0u, n_groups, v, mask); });
+    }
+    timeit("D read floor, tile walk u1", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 1, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    timeit("D read floor, tile walk u2", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 2, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    timeit("D read floor, tile walk u4", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    timeit("D read floor, tile walk u4 nt", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    timeit("D read floor, tile walk u1 nt", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 1, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    for (int bpc : {4, 8})  {
+        char nm[64]; snprintf(nm, sizeof nm, "D read floor, strided u1, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL((read_floor_kernel<true, 1, false>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+        snprintf(nm, sizeof nm, "D read floor, strided u4 nt, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL((read_floor_kernel<true, 4, true>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    }
+    return 0;
+}

@@ -22,7 +22,8 @@ namespace mcull {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr uint32_t kTileGroups = 256;  // groups per workgroup tile = 16384 meshlet-instances
+constexpr uint32_t kTileGroups = 256;  // groups per compaction tile = 16384 meshlet-instances
+constexpr uint32_t kSuperTiles = 256;  // tiles per super-tile (second level of the offset sums)
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax * bx + ay * by) + az * bz;
@@ -52,14 +53,18 @@ struct Xform {
     float4 c0, c1, c2, c3;  // columns of the model matrix
 };
 
+// length(transform.model[0].xyz) (shader.task:99): uniform per instance, so it is evaluated once
+// per uploaded transform (same expression, same rounding) instead of once per pair.
+__device__ __forceinline__ float xform_scale(float4 c0) { return sqrtf(dot3(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z)); }
+
 // shader.task:85-101 for one pair.  `a` = {axis.xyz, coneW}, `c` = {centre.xyz, radius}.
 template <uint32_t TESTS>
-__device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float4 a, float4 c) {
+__device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float scale, float4 a, float4 c) {
     // world-space centre (shader.task:91), axis (:95), radius (:99)
     const float wx = ((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x;
     const float wy = ((m.c0.y * c.x + m.c1.y * c.y) + m.c2.y * c.z) + m.c3.y;
     const float wz = ((m.c0.z * c.x + m.c1.z * c.y) + m.c2.z * c.z) + m.c3.z;
-    const float r = c.w * sqrtf(dot3(m.c0.x, m.c0.y, m.c0.z, m.c0.x, m.c0.y, m.c0.z));
+    const float r = c.w * scale;  // scale = length(model[0].xyz), evaluated once per instance
 
     bool culled = false;
     if (TESTS & MCULL_TEST_FRUSTUM) {  // frustumCull, shader.task:43-56
@@ -131,57 +136,67 @@ __device__ __forceinline__ Xform load_xform(const float4 *__restrict__ transform
     return m;
 }
 
+// 16-byte load of one SoA element; NT = streaming (non-temporal) hint for bounds arrays far larger
+// than the caches, which are read exactly once per cull.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 load_bounds(const float4 *__restrict__ p) {
+    if (NT) {
+        const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+        return make_float4(q.x, q.y, q.z, q.w);
+    }
+    return *p;
+}
+
 // ------------------------------------------------------------------------------------------------
-// ordered, pass 1: visibility ballots.  One workgroup per tile of kTileGroups groups; wave w takes
-// groups tile*256 + w, +4, +8 ...  The bounds of the next group are requested before the current
-// group is evaluated, so every wave keeps two 2-KiB requests in flight.
-template <uint32_t TESTS>
+// ordered, pass 1: visibility ballots.  Small workgroups: each of the 4 waves takes NG consecutive
+// groups, requests all their bounds up front (NG x 2 KiB in flight per wave), evaluates them and
+// stores NG ballot words.  The workgroup's visible count is added to its 256-group tile's counter
+// (one atomic per workgroup, 256/(4*NG) per counter; the counters are zero on entry and re-zeroed
+// by emit_commands_kernel).
+template <uint32_t TESTS, int NG, bool NT>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
-    const float4 *__restrict__ transforms, const uint4 *__restrict__ group_rec,
-    uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
+    const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
     uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts) {
     __shared__ uint32_t s_count[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t g_begin = blockIdx.x * kTileGroups;
-    const uint32_t g_end = min(g_begin + kTileGroups, n_groups);
-    uint32_t count = 0;
-
-    uint32_t g = g_begin + wave;
-    GroupInfo gi = {0, 0, 0, 0};
-    Xform m = {};
-    float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
-    if (g < g_end) {
-        gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
-        m = load_xform(transforms, gi.inst);
-        if (lane < gi.count) {
-            a = cone_axis_w[gi.first_meshlet + lane];
-            c = centre_radius[gi.first_meshlet + lane];
-        }
+    const uint32_t block_g0 = blockIdx.x * (kWaves * NG);
+    const uint32_t g0 = block_g0 + wave * NG;
+    GroupInfo gi[NG];
+    Xform m[NG];
+    float scale[NG];
+    float4 a[NG], c[NG];
+    // All loads are unconditional (out-of-range groups and lanes re-read a valid element) so that
+    // the 2*NG bounds requests of a wave are issued back to back before the first wait.
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const bool valid = g0 + k < n_groups;
+        gi[k] = group_lookup(valid ? g0 + k : n_groups - 1u, group_rec, groups_per_instance, v.uniform_count);
+        if (!valid) gi[k].count = 0;
+        m[k] = load_xform(transforms, gi[k].inst);
+        scale[k] = xf_scale[gi[k].inst];
+        const uint32_t last = gi[k].count ? gi[k].count - 1u : 0u;
+        const uint32_t id = gi[k].first_meshlet + (lane < last ? lane : last);
+        a[k] = load_bounds<NT>(cone_axis_w + id);
+        c[k] = load_bounds<NT>(centre_radius + id);
     }
-    while (g < g_end) {
-        const uint32_t gn = g + kWaves;
-        GroupInfo gin = {0, 0, 0, 0};
-        Xform mn = {};
-        float4 an = make_float4(0, 0, 0, 0), cn = make_float4(0, 0, 0, 0);
-        if (gn < g_end) {
-            gin = group_lookup(gn, group_rec, groups_per_instance, v.uniform_count);
-            mn = load_xform(transforms, gin.inst);
-            if (lane < gin.count) {
-                an = cone_axis_w[gin.first_meshlet + lane];
-                cn = centre_radius[gin.first_meshlet + lane];
-            }
-        }
-        const bool vis = (lane < gi.count) && pair_visible<TESTS>(v, m, a, c);
+    uint32_t count = 0;
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
         const uint64_t ballot = __ballot(vis);
-        if (lane == 0) mask[g] = ballot;
+        if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
         count += (uint32_t)__popcll(ballot);
-        g = gn; gi = gin; m = mn; a = an; c = cn;
     }
     if (lane == 0) s_count[wave] = count;
     __syncthreads();
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
+    if (threadIdx.x == 0) {
+        const uint32_t sum = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
+        if (sum) atomicAdd(&tile_counts[block_g0 / kTileGroups], sum);
+    }
 }
 
 // exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
@@ -209,52 +224,52 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered, between the passes: exclusive prefix of the per-tile visible counts (one workgroup).
-constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
-                                                                unsigned long long *__restrict__ tile_base,
-                                                                unsigned long long *__restrict__ total) {
-    __shared__ unsigned long long s_wave[kScanBlock / 64];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += kScanBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const unsigned long long x = i < n_tiles ? tile_counts[i] : 0ull;
-        unsigned long long incl = x;
+// Scenes with more than kSuperTiles * 16 tiles: sum of each run of kSuperTiles tile counters, so
+// that the scatter pass reads at most n_tiles/256 + 255 counters per workgroup instead of n_tiles.
+__global__ __launch_bounds__(kBlock) void super_sum_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
+                                                           uint32_t *__restrict__ super_counts) {
+    __shared__ uint32_t s_sum[kWaves];
+    const uint32_t j = blockIdx.x * kSuperTiles + threadIdx.x;
+    uint32_t x = j < n_tiles ? tile_counts[j] : 0u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long up = __shfl_up(incl, d, 64);
-            if (lane >= (uint32_t)d) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        unsigned long long wave_base = 0, chunk_total = 0;
-#pragma unroll
-        for (int w = 0; w < kScanBlock / 64; w++) {
-            const unsigned long long t = s_wave[w];
-            if ((uint32_t)w < wave) wave_base += t;
-            chunk_total += t;
-        }
-        if (i < n_tiles) tile_base[i] = carry + wave_base + incl - x;
-        carry += chunk_total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) super_counts[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered, pass 2: scatter.  One workgroup per tile, one group per thread for the scan, then one
-// group per wave-iteration for the stores (lane l owns bit l; slots are contiguous per group).
+// ordered, pass 2: scatter.  One workgroup per 256-group tile.  Its list offset is the number of
+// visible pairs in all lower tiles: the sum of the lower tile counters (read from L2), or, for
+// very large scenes, of the lower super-tile sums plus the lower counters of its own super-tile.  Then one group per
+// thread for the in-tile scan, and one group per wave-iteration for the stores (lane l owns bit l,
+// the slots of a group are contiguous).
 __global__ __launch_bounds__(kBlock) void compact_kernel(
-    const uint64_t *__restrict__ mask, const unsigned long long *__restrict__ tile_base,
-    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups,
-    mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first) {
+    const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
+    const uint32_t *__restrict__ super_counts, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
+    uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
+    unsigned long long *__restrict__ total) {
     __shared__ uint64_t s_word[kBlock];
     __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
     __shared__ uint32_t s_wave[kWaves];
+    __shared__ unsigned long long s_sum[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long running = tile_base[blockIdx.x];
+    unsigned long long part = 0;
+    if (super_counts) {
+        const uint32_t super = blockIdx.x / kSuperTiles;
+        for (uint32_t j = threadIdx.x; j < super; j += kBlock) part += super_counts[j];
+        const uint32_t j = super * kSuperTiles + threadIdx.x;  // kSuperTiles == kBlock
+        if (j < blockIdx.x) part += tile_counts[j];
+    } else {
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += tile_counts[j];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) s_sum[wave] = part;
+    __syncthreads();
+    const unsigned long long running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + tile_counts[blockIdx.x];
     const uint32_t tile = blockIdx.x * kTileGroups;
     const uint32_t g_end = min(tile + kTileGroups, n_groups);
     const uint32_t g = tile + threadIdx.x;
@@ -307,8 +322,11 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
     const uint2 *__restrict__ ranges, uint32_t uniform_count, uint32_t n_instances,
     const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
-    uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands) {
+    uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
+    uint32_t *__restrict__ tile_counts, uint32_t n_tiles) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // every consumer of the tile counters has finished (stream order): leave them zero for the next cull
+    if (tile_counts && i < n_tiles) tile_counts[i] = 0;
     if (i >= n_instances) return;
     unsigned long long base = 0;
     if (rank_totals)
@@ -340,8 +358,8 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
 template <uint32_t TESTS, bool BLOCK>
 __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
-    const float4 *__restrict__ transforms, const uint4 *__restrict__ group_rec,
-    uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
+    const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
     mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_count,
     unsigned long long *__restrict__ total, uint64_t *__restrict__ mask) {
     __shared__ uint32_t s_pop[2][kWaves];
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
             const Xform m = load_xform(transforms, gi.inst);
             if (lane < gi.count) {
                 const uint32_t id = gi.first_meshlet + lane;
-                vis = pair_visible<TESTS>(v, m, cone_axis_w[id], centre_radius[id]);
+                vis = pair_visible<TESTS>(v, m, xf_scale[gi.inst], cone_axis_w[id], centre_radius[id]);
             }
         }
         const uint64_t ballot = __ballot(vis);
@@ -399,6 +417,13 @@ __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void xform_scale_kernel(const float4 *__restrict__ transforms, uint32_t n,
+                                                             float *__restrict__ xf_scale) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) xf_scale[i] = xform_scale(transforms[(size_t)i * 4]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,38 +481,53 @@ uint32_t tile_count_for(uint64_t n_groups) { return (uint32_t)((n_groups + kTile
         default: { constexpr uint32_t T = 7; CALL; break; }                      \
     }
 
-hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                            hipStream_t st) {
-    const uint32_t grid = tile_count_for(s.n_groups);
-    MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL(cull_mask_kernel<T>, dim3(grid), dim3(kBlock), 0, st,
-                                                     s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+uint32_t super_count_for(uint64_t n_groups) { return (tile_count_for(n_groups) + kSuperTiles - 1) / kSuperTiles; }
+bool needs_super_counts(uint64_t n_groups) { return tile_count_for(n_groups) > kSuperTiles * 16u; }
+
+template <int NG, bool NT>
+static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
+                               hipStream_t st) {
+    const uint32_t per_block = kWaves * NG;
+    const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
+    MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
+                                                     s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                      s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts));
+}
+
+hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
+                            bool streaming, hipStream_t st) {
+    if (streaming) launch_cull_mask_t<2, true>(s, v, mask, tile_counts, st);
+    else launch_cull_mask_t<2, false>(s, v, mask, tile_counts, st);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_tiles(const uint32_t *tile_counts, uint32_t n_tiles, uint64_t *tile_base, uint64_t *total,
-                             hipStream_t st) {
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanBlock), 0, st, tile_counts, n_tiles,
-                       (unsigned long long *)tile_base, (unsigned long long *)total);
-    return hipGetLastError();
-}
-
-hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint64_t *tile_base, mcull_visible *list,
-                          uint64_t capacity, uint32_t *inst_first, hipStream_t st) {
+// super_counts may be nullptr (scenes up to kSuperTiles*16 tiles)
+hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
+                          uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
+                          uint64_t *total, hipStream_t st) {
     const uint32_t grid = tile_count_for(s.n_groups);
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kBlock), 0, st, mask, (const unsigned long long *)tile_base,
-                       s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first);
+    if (super_counts) {
+        hipLaunchKernelGGL(super_sum_kernel, dim3(super_count_for(s.n_groups)), dim3(kBlock), 0, st, tile_counts, grid,
+                           super_counts);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, super_counts, s.group_rec,
+                       s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
+                       (unsigned long long *)total);
     return hipGetLastError();
 }
 
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
-                                uint32_t rank, CmdLayout lay, void *commands, hipStream_t st) {
-    if (s.n_instances == 0) return hipSuccess;
-    const uint32_t grid = (s.n_instances + kBlock - 1) / kBlock;
+                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st) {
+    const uint32_t n_tiles = tile_counts ? tile_count_for(s.n_groups) : 0;
+    const uint32_t work = s.n_instances > n_tiles ? s.n_instances : n_tiles;
+    if (work == 0) return hipSuccess;
+    const uint32_t grid = (work + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, uniform_count, s.n_instances,
                        inst_first, inst_count, total, rank_totals, rank, lay.stride, lay.offset, lay.form,
-                       (uint8_t *)commands);
+                       (uint8_t *)commands, tile_counts, n_tiles);
     return hipGetLastError();
 }
 
@@ -496,15 +536,21 @@ hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visib
     const uint32_t grid = tile_count_for(s.n_groups);
     if (block_mode) {
         MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_atomic_kernel<T, true>), dim3(grid), dim3(kBlock), 0, st,
-                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                          s.groups_per_instance, (uint32_t)s.n_groups, v, list, capacity,
                                                          inst_count, (unsigned long long *)total, mask));
     } else {
         MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_atomic_kernel<T, false>), dim3(grid), dim3(kBlock), 0, st,
-                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.group_rec,
+                                                         s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                          s.groups_per_instance, (uint32_t)s.n_groups, v, list, capacity,
                                                          inst_count, (unsigned long long *)total, mask));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_xform_scale(const float4 *transforms, uint32_t n, float *xf_scale, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(xform_scale_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, transforms, n, xf_scale);
     return hipGetLastError();
 }
 

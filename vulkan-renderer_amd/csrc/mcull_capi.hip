@@ -41,7 +41,7 @@ struct mcull_ctx {
     std::string err;
 
     // scene
-    DevBuf aos, cone, sphere, vertices, mdata, transforms, ranges, group_base, group_rec;
+    DevBuf aos, cone, sphere, vertices, mdata, transforms, xf_scale, ranges, group_base, group_rec;
     uint64_t n_meshlets = 0, n_vertices = 0, n_words = 0, n_instances = 0;
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
     uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
@@ -52,7 +52,8 @@ struct mcull_ctx {
     bool hiz_single_pass = true;
 
     // cull scratch + outputs
-    DevBuf mask, tile_counts, tile_base, inst_first, inst_count, total, list, commands;
+    DevBuf mask, tile_counts, super_counts, inst_first, inst_count, total, list, commands;
+    bool counters_clean = false;  // tile/super counters are all zero (K1 adds into them, K4 re-zeroes)
     uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
     // description of the last cull (for rebase / downloads / payloads)
     struct Last {
@@ -219,8 +220,8 @@ int mcull_destroy(mcull_ctx *c) {
     if (!c) return MCULL_E_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->mask, &c->tile_counts, &c->tile_base,
+    DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->mask, &c->tile_counts, &c->super_counts,
                       &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands};
     for (DevBuf *b : bufs) release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
@@ -356,7 +357,10 @@ int mcull_upload_transforms(mcull_ctx *c, const mcull_transform *transforms, uin
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->transforms, count * sizeof(mcull_transform)))) return rc;
+    if ((rc = ensure(c, c->xf_scale, count * 4))) return rc;
     if ((rc = copy_in(c, c->transforms.p, transforms, count * sizeof(mcull_transform), mem))) return rc;
+    HIPCHK(c, mcull::launch_xform_scale((const float4 *)c->transforms.p, (uint32_t)count, (float *)c->xf_scale.p,
+                                        c->stream));
     c->n_instances = count;
     c->last.valid = false;
     return MCULL_OK;
@@ -501,6 +505,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     s.cone_axis_w = (const float4 *)c->cone.p;
     s.centre_radius = (const float4 *)c->sphere.p;
     s.transforms = (const float4 *)c->transforms.p;
+    s.xf_scale = (const float *)c->xf_scale.p;
     s.n_instances = (uint32_t)c->n_instances;
     uint64_t n_pairs;
     uint32_t uniform_count = 0;
@@ -568,18 +573,26 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
         HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands, nullptr, c->stream));
     } else if (p.compaction == MCULL_COMPACT_ORDERED) {
+        const bool two_level = mcull::needs_super_counts(s.n_groups);
+        if (!c->tile_counts.p || c->tile_counts.cap < (size_t)n_tiles * 4) c->counters_clean = false;
         if ((rc = ensure(c, c->tile_counts, (size_t)n_tiles * 4))) return rc;
-        if ((rc = ensure(c, c->tile_base, (size_t)n_tiles * 8))) return rc;
+        if (two_level && (rc = ensure(c, c->super_counts, (size_t)mcull::super_count_for(s.n_groups) * 4))) return rc;
         if ((rc = ensure(c, c->inst_first, (c->n_instances + 1) * 4))) return rc;
-        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->tile_counts.p, c->stream));
-        HIPCHK(c, mcull::launch_scan_tiles((const uint32_t *)c->tile_counts.p, n_tiles, (uint64_t *)c->tile_base.p, total,
-                                           c->stream));
-        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint64_t *)c->tile_base.p, list, capacity,
-                                        (uint32_t *)c->inst_first.p, c->stream));
+        if (!c->counters_clean) HIPCHK(c, hipMemsetAsync(c->tile_counts.p, 0, c->tile_counts.cap, c->stream));
+        c->counters_clean = false;  // until the command kernel that re-zeroes them has been enqueued
+        // bounds that cannot stay cache-resident between culls are read with the streaming hint
+        const bool streaming = c->n_meshlets * 32ull > (64ull << 20);
+        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->tile_counts.p, streaming,
+                                          c->stream));
+        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->tile_counts.p,
+                                        two_level ? (uint32_t *)c->super_counts.p : nullptr, list, capacity,
+                                        (uint32_t *)c->inst_first.p, total, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands,
+                                              (uint32_t *)c->tile_counts.p, c->stream));
+        c->counters_clean = true;
     } else {
         if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
         HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
@@ -588,7 +601,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
                                             p.write_mask ? (uint64_t *)c->mask.p : nullptr,
                                             p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands, c->stream));
+                                              (const uint64_t *)total, nullptr, 0, lay, commands, nullptr, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -625,7 +638,7 @@ int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t 
                                           ordered ? (const uint32_t *)c->inst_first.p : nullptr,
                                           ordered ? nullptr : (const uint32_t *)c->inst_count.p,
                                           (const uint64_t *)c->total_ptr, device_totals, rank, c->last.lay,
-                                          c->last.commands, c->stream));
+                                          c->last.commands, nullptr, c->stream));
     return MCULL_OK;
 }
 

@@ -33,6 +33,7 @@ struct SceneDev {
     const float4 *cone_axis_w;    // {axis.xyz, coneW} per meshlet
     const float4 *centre_radius;  // {centre.xyz, radius} per meshlet
     const float4 *transforms;     // 4 x float4 (column-major mat4) per instance
+    const float *xf_scale;        // length(model[0].xyz) per instance
     const uint2 *ranges;          // {meshletOffset, meshletCount} per instance, or nullptr
     const uint4 *group_rec;       // {instance, first meshlet, count, local group} per 64-meshlet group, or nullptr
     uint32_t n_instances;
@@ -46,17 +47,19 @@ struct CmdLayout {
 
 // ---- launchers (each returns the hipError_t of the launch) ----
 uint32_t tile_count_for(uint64_t n_groups);
+uint32_t super_count_for(uint64_t n_groups);
+bool needs_super_counts(uint64_t n_groups);
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                            hipStream_t st);
-hipError_t launch_scan_tiles(const uint32_t *tile_counts, uint32_t n_tiles, uint64_t *tile_base, uint64_t *total,
-                             hipStream_t st);
-hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint64_t *tile_base, mcull_visible *list,
-                          uint64_t capacity, uint32_t *inst_first, hipStream_t st);
+                            bool streaming, hipStream_t st);
+hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
+                          uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
+                          uint64_t *total, hipStream_t st);
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
-                                uint32_t rank, CmdLayout lay, void *commands, hipStream_t st);
+                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st);
 hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
                               uint32_t *inst_count, uint64_t *total, uint64_t *mask, bool block_mode, hipStream_t st);
+hipError_t launch_xform_scale(const float4 *transforms, uint32_t n, float *xf_scale, hipStream_t st);
 hipError_t launch_fill_group_rec(const uint2 *ranges, const uint32_t *group_base, uint32_t n_instances,
                                  uint4 *group_rec, hipStream_t st);
 hipError_t launch_task_payloads(const SceneDev &s, const uint64_t *mask, mcull_task_payload *out, uint64_t n_payloads,
