@@ -82,6 +82,17 @@ __global__ __launch_bounds__(kBlock) void read_floor_kernel(const float4 *__rest
     }
 }
 
+// stand-in for the compaction pass's output traffic: n8 8-byte entries
+template <bool NT>
+__global__ __launch_bounds__(256) void write_kernel(unsigned long long *out, size_t n8) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n8; i += stride) {
+        if (NT) __builtin_nontemporal_store((unsigned long long)i, out + i);
+        else out[i] = i;
+    }
+}
+
 int main(int argc, char **argv) {
     const uint32_t n_inst = 781250, per = 128;
     const uint64_t n = (uint64_t)n_inst * per;
@@ -161,6 +172,31 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
         uint64_t vis = 0; for (auto w : hm) vis += __builtin_popcountll(w);
         printf("visible fraction %.3f\n", (double)vis / n);
+    }
+    {
+        unsigned long long *wbuf; const size_t n8 = 51400000; CK(hipMalloc(&wbuf, n8 * 8));
+        hipEvent_t ev[64]; for (auto &e : ev) CK(hipEventCreate(&e));
+        for (int nt = 0; nt < 2; nt++) {
+            for (int rep = 0; rep < 2; rep++) {
+                for (int i = 0; i < 10; i++) {
+                    CK(hipEventRecord(ev[3 * i]));
+                    hipLaunchKernelGGL((cull_mask_kernel<3, 2, true>), dim3((n_groups + 7) / 8), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
+                    CK(hipEventRecord(ev[3 * i + 1]));
+                    if (nt) hipLaunchKernelGGL(write_kernel<true>, dim3(2048), dim3(256), 0, 0, wbuf, n8);
+                    else hipLaunchKernelGGL(write_kernel<false>, dim3(2048), dim3(256), 0, 0, wbuf, n8);
+                    CK(hipEventRecord(ev[3 * i + 2]));
+                }
+                CK(hipEventRecord(ev[30]));
+                CK(hipDeviceSynchronize());
+            }
+            float k1 = 0, wr = 0, tot = 0, ms;
+            for (int i = 0; i < 10; i++) {
+                CK(hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1])); k1 += ms;
+                CK(hipEventElapsedTime(&ms, ev[3 * i + 1], ev[3 * i + 2])); wr += ms;
+            }
+            CK(hipEventElapsedTime(&tot, ev[0], ev[30]));
+            printf("alternating K1 / 411 MB %s write: K1 %.1f us, write %.1f us, pair %.1f us\n", nt ? "nt" : "plain", k1 * 100, wr * 100, tot * 100);
+        }
     }
     for (int bpc : {6, 12}) {
         char nm[64]; snprintf(nm, sizeof nm, "B strided persistent, %d blocks/CU", bpc);

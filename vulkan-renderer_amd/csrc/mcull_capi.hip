@@ -588,7 +588,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
                                           c->stream));
         HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->tile_counts.p,
                                         two_level ? (uint32_t *)c->super_counts.p : nullptr, list, capacity,
-                                        (uint32_t *)c->inst_first.p, total, c->stream));
+                                        (uint32_t *)c->inst_first.p, total, n_pairs * 8ull > (64ull << 20), c->stream));
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
                                               (const uint64_t *)total, nullptr, 0, lay, commands,
                                               (uint32_t *)c->tile_counts.p, c->stream));

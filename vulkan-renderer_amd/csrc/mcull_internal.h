@@ -53,7 +53,7 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
                             bool streaming, hipStream_t st);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
-                          uint64_t *total, hipStream_t st);
+                          uint64_t *total, bool streaming, hipStream_t st);
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
                                 uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st);
