@@ -90,6 +90,7 @@ def main():
 
     mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
     host = importlib.import_module("vulkan-renderer_amd.host")
+    mdist = importlib.import_module("vulkan-renderer_amd.dist")
     ctx = mc.Context(local_rank)
 
     n_inst, per = args.instances, args.meshlets_per_instance
@@ -111,17 +112,13 @@ def main():
     lst = torch.empty((n_pairs, 2), device=device, dtype=torch.int32)
     cmds = torch.zeros((n_inst, 2), device=device, dtype=torch.int32)
     total = torch.zeros(1, device=device, dtype=torch.int64)
-    totals_all = torch.zeros(world, device=device, dtype=torch.int64)
-    cmds_all = torch.empty((world * n_inst, 2), device=device, dtype=torch.int32) if world > 1 else None
     kernel_ms = []
 
     def step(record):
         ctx.cull(g, tests=tests, compaction=args.compaction, list_ptr=lst.data_ptr(), list_capacity=n_pairs,
                  commands_ptr=cmds.data_ptr(), total_ptr=total.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(totals_all, total)
-            ctx.rebase_commands(totals_all.data_ptr(), rank)
-            dist.all_gather_into_tensor(cmds_all, cmds)
+            mdist.gather_draw_list(total, cmds, lambda totals, rk: ctx.rebase_commands(totals.data_ptr(), rk))
         if record:
             kernel_ms.append(ctx.last_kernel_ms())
 
@@ -153,7 +150,8 @@ def main():
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    # separate, untimed steps for the per-kernel device time (the event read-back synchronises)
+    # separate, untimed steps for the per-call device time (the event read-back synchronises)
+    ctx.enable_timing(True)
     for _ in range(min(args.steps, 10)):
         step(True)
     visible = int(total.item())

@@ -257,9 +257,12 @@ int mcull_download_list(mcull_ctx *ctx, mcull_visible *out, uint64_t capacity, u
 int mcull_download_commands(mcull_ctx *ctx, void *out, uint64_t bytes);
 int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
 
-/* Device time of the kernels of the last mcull_cull / mcull_hiz_build /
- * mcull_compute_bounds in milliseconds (HIP events on the context's stream;
- * the reference's timestamp queries, Engine.cpp:2393-2394, :2548). Synchronous. */
+/* Device timestamps around the kernels of each mcull_cull / mcull_hiz_build /
+ * mcull_compute_bounds (HIP events on the context's stream; the reference's timestamp
+ * queries, Engine.cpp:2393-2394, :2548).  Off by default: the two event records cost a few
+ * microseconds of stream time per call. */
+int mcull_enable_timing(mcull_ctx *ctx, int enable);
+/* Milliseconds between the two timestamps of the last timed call. Synchronous. */
 int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
 
 #ifdef __cplusplus

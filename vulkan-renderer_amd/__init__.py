@@ -55,7 +55,8 @@ ABI_SYMBOLS = [
     "mcull_download_meshlets", "mcull_upload_transforms", "mcull_set_instance_ranges", "mcull_hiz_level_count",
     "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
     "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
-    "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_last_kernel_ms",
+    "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_enable_timing",
+    "mcull_last_kernel_ms",
 ]
 
 
@@ -103,6 +104,7 @@ _sig("mcull_download_count", _I, [_P, C.POINTER(_U64)])
 _sig("mcull_download_list", _I, [_P, _P, _U64, C.POINTER(_U64)])
 _sig("mcull_download_commands", _I, [_P, _P, _U64])
 _sig("mcull_download_mask", _I, [_P, _P, _U64])
+_sig("mcull_enable_timing", _I, [_P, _I])
 _sig("mcull_last_kernel_ms", _I, [_P, C.POINTER(C.c_float)])
 
 
@@ -282,6 +284,9 @@ class Context:
         self._chk(lib.mcull_emit_task_payloads(self._h, buf.data_ptr()))
         self.synchronize()
         return np.frombuffer(buf.cpu().numpy().tobytes(), dtype=TASK_PAYLOAD)[:n]
+
+    def enable_timing(self, on=True):
+        self._chk(lib.mcull_enable_timing(self._h, int(bool(on))))
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -37,7 +37,8 @@ struct mcull_ctx {
     int cu_count = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    bool timed = false;       // a pair of timestamps has been recorded
+    bool timing = false;      // record timestamps around kernels
     std::string err;
 
     // scene
@@ -330,12 +331,14 @@ int mcull_compute_bounds(mcull_ctx *c) {
                     return fail(c, MCULL_E_INVALID, "meshlet %llu: local index out of range", (unsigned long long)i);
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_bounds((const mcull_vertex *)c->vertices.p, (const uint32_t *)c->mdata.p,
                                    (mcull_meshlet *)c->aos.p, c->n_meshlets, (float4 *)c->cone.p, (float4 *)c->sphere.p,
                                    c->stream));
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
     c->have_bounds = true;
     return MCULL_OK;
 }
@@ -452,11 +455,13 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
         src = (const float *)c->depth_staging.p;
     }
     s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
                                 (uint32_t *)c->hiz_counter.p, c->hiz_single_pass, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
     s.built = true;
     return MCULL_OK;
 }
@@ -567,7 +572,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     const uint32_t n_tiles = mcull::tile_count_for(s.n_groups);
     const mcull::CmdLayout lay{p.cmd_stride, p.cmd_offset, p.cmd_form};
 
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (s.n_groups == 0) {
         HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
         if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
@@ -603,8 +608,10 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
                                               (const uint64_t *)total, nullptr, 0, lay, commands, nullptr, c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
 
     c->last.valid = true;
     c->total_ptr = total;
@@ -709,6 +716,13 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
         HIPCHK(c, hipMemcpyAsync(out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return MCULL_OK;
+}
+
+int mcull_enable_timing(mcull_ctx *c, int enable) {
+    if (!c) return MCULL_E_INVALID;
+    c->timing = enable != 0;
+    if (!c->timing) c->timed = false;
     return MCULL_OK;
 }
 

@@ -1,0 +1,43 @@
+"""Multi-GPU glue: instances shard across ranks (one process per GPU), every rank culls its own
+shard, and two small all-gathers turn the per-rank results into one global draw list description:
+
+  1. all-gather of each rank's visible count (8 bytes per rank);
+  2. every rank rebases its per-instance firstTask by the sum of the lower ranks' counts
+     (on the device for the GPU path: mcull_rebase_commands reads the gathered counts);
+  3. all-gather of the per-instance indirect commands.
+
+The reference is single-GPU (Engine.cpp:658-666 picks one device); this has no counterpart there.
+torch.distributed is the transport ("nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_instances(n_instances, world, rank, weights=None):
+    """Contiguous instance range [begin, end) of `rank`.  With `weights` (meshlets per instance) the
+    cut points balance the summed weight instead of the instance count."""
+    if weights is None:
+        return (n_instances * rank) // world, (n_instances * (rank + 1)) // world
+    import numpy as np
+
+    cum = np.concatenate([[0], np.cumsum(np.asarray(weights, dtype=np.int64))])
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, (total * r) // world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n_instances
+    return cuts[rank], cuts[rank + 1]
+
+
+def gather_draw_list(total_local, cmds_local, rebase, group=None):
+    """total_local: int64 tensor [1]; cmds_local: int32 tensor [n_local, 2] = {taskCount, firstTask}
+    with rank-local firstTask; rebase(totals_all, rank) must add sum(totals_all[:rank]) to every
+    firstTask of cmds_local in place (stream-ordered).  Every rank must hold the same n_local
+    (pad the last shard) because all_gather_into_tensor needs equal sizes.
+    Returns (totals_all [world], cmds_all [world * n_local, 2])."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    totals_all = torch.empty(world, dtype=torch.int64, device=total_local.device)
+    dist.all_gather_into_tensor(totals_all, total_local, group=group)
+    rebase(totals_all, rank)
+    cmds_all = torch.empty((world * cmds_local.shape[0], 2), dtype=cmds_local.dtype, device=cmds_local.device)
+    dist.all_gather_into_tensor(cmds_all, cmds_local, group=group)
+    return totals_all, cmds_all
