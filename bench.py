@@ -163,6 +163,7 @@ def main():
         n_hz = 0
         algo = 32.0 * n_pairs + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible + 4.0 * n_hz
         achieved = algo / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args, n_inst, per)
         out = {
             "metric": "meshlet-instances culled+compacted/sec", "value": round(value, 3), "unit": "G/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -176,7 +177,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)",
                 "kernel_ms": round(k_ms, 4), "kernel_ms_single_call": round(float(np.mean(kernel_ms)), 4),
                 "algorithmic_bytes": int(algo),
@@ -190,6 +191,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic(args, n_inst, per):
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE
+    doubled as the gfx950 correction prescribes, WRITE_SIZE as is; separate passes), or None when the
+    workload differs from the profiled one.  Counters cannot be collected from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_config4_summary.json")
+    if (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False) or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        summ = json.load(f)
+    total = 0
+    for name, row in summ.items():
+        if any(k in name for k in ("cull_mask_kernel", "compact_kernel", "emit_commands_kernel")):
+            total += row.get("fetch_bytes_corrected", 0) + row.get("write_bytes_corrected", 0)
+    return (total or None), "profiles/r01_bench_config4_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
 
 
 def cpu_baseline(cone, sphere, xf, off, cnt, g, tests, n_inst, per):

@@ -1,0 +1,118 @@
+// mcull.hpp — C++17 host-side wrapper over the C ABI (mcull.h), header-only.
+//
+// The method names mirror the reference's Engine methods for this path so that host code written
+// against the reference reads the same, and errors behave like the reference's VK_CHECK
+// (utils.hpp:68-79): the failure is printed to stderr and a std::runtime_error is thrown.
+//
+//   reference (Engine.cpp)                     this wrapper
+//   createMeshletBuffer          :1427-1453    Culler::createMeshletBuffer
+//   createVertexBuffer/MeshletDataBuffer       Culler::createGeometryBuffers
+//   buildMeshletCon              :472-547      Culler::buildMeshletCones        (GPU)
+//   updateTransforms (memcpy)    :2378         Culler::updateTransforms
+//   createHiZPyramid+buildHiZPyramid :1658,:1834  Culler::buildHiZPyramid
+//   vkCmdPushConstants + vkCmdDrawMeshTasksIndirectNV :2535-2539   Culler::cull
+//   createIndirectBuffer         :1466-1506    written by Culler::cull (dynamic)
+#pragma once
+
+#include <cstdint>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mcull.h"
+
+#define MCULL_CHECK(ctx, expr)                                                                        \
+    do {                                                                                              \
+        int mcull_status_ = (expr);                                                                   \
+        if (mcull_status_ != MCULL_OK) {                                                              \
+            std::string mcull_msg_ = std::string("mcull error: ") + mcull_status_string(mcull_status_) + \
+                                     " (" + ((ctx) ? mcull_last_error(ctx) : "no context") + ")";    \
+            std::cerr << mcull_msg_ << " in " << __FILE__ << " at line " << __LINE__ << std::endl;   \
+            throw std::runtime_error(mcull_msg_);                                                     \
+        }                                                                                             \
+    } while (0)
+
+namespace mcull {
+
+using Vertex = mcull_vertex;
+using Meshlet = mcull_meshlet;
+using Globals = mcull_globals;
+using Transform = mcull_transform;
+using DrawMeshTasksIndirectCommandNV = mcull_mesh_tasks_cmd;
+using DrawIndirect = mcull_draw_indirect;
+using Visible = mcull_visible;
+
+static_assert(sizeof(Vertex) == 24 && sizeof(Meshlet) == 48 && sizeof(Globals) == 212 && sizeof(Transform) == 64 &&
+                  sizeof(DrawMeshTasksIndirectCommandNV) == 8 && sizeof(DrawIndirect) == 28 && sizeof(Visible) == 8,
+              "layout contract of shaders/common.h / Engine.hpp");
+
+class Culler {
+public:
+    explicit Culler(int device = 0, void *hip_stream = nullptr) { MCULL_CHECK(ctx_, mcull_create(device, hip_stream, &ctx_)); }
+    ~Culler() {
+        if (ctx_) mcull_destroy(ctx_);
+    }
+    Culler(const Culler &) = delete;
+    Culler &operator=(const Culler &) = delete;
+
+    // binding 2 (shader.task:22-24)
+    void createMeshletBuffer(const std::vector<Meshlet> &meshlets) {
+        meshletCount_ = meshlets.size();
+        MCULL_CHECK(ctx_, mcull_upload_meshlets(ctx_, meshlets.data(), meshlets.size(), MCULL_MEM_HOST));
+    }
+    // bindings 1 and 3 (shader.mesh:27-37)
+    void createGeometryBuffers(const std::vector<Vertex> &vertices, const std::vector<uint32_t> &meshletData) {
+        MCULL_CHECK(ctx_, mcull_upload_geometry(ctx_, vertices.data(), vertices.size(), meshletData.data(),
+                                                meshletData.size(), MCULL_MEM_HOST));
+    }
+    // Engine::buildMeshletCon for every meshlet, on the GPU; returns the completed records
+    std::vector<Meshlet> buildMeshletCones() {
+        MCULL_CHECK(ctx_, mcull_compute_bounds(ctx_));
+        std::vector<Meshlet> out(meshletCount_);
+        MCULL_CHECK(ctx_, mcull_download_meshlets(ctx_, out.data(), out.size()));
+        return out;
+    }
+    // binding 4 (shader.task:18-20)
+    void updateTransforms(const std::vector<Transform> &transforms) {
+        instances_ = transforms.size();
+        MCULL_CHECK(ctx_, mcull_upload_transforms(ctx_, transforms.data(), transforms.size(), MCULL_MEM_HOST));
+    }
+    void setInstanceRanges(const std::vector<uint32_t> &offset, const std::vector<uint32_t> &count) {
+        MCULL_CHECK(ctx_, mcull_set_instance_ranges(ctx_, offset.data(), count.data(), offset.size()));
+    }
+    // binding 5 (shader.task:26): all levels of the pyramid in one launch
+    void buildHiZPyramid(const float *depth, uint32_t width, uint32_t height, uint32_t view = 0, bool on_device = false) {
+        MCULL_CHECK(ctx_, mcull_hiz_build(ctx_, view, depth, width, height, on_device ? MCULL_MEM_DEVICE : MCULL_MEM_HOST));
+    }
+    // the task shader over every (instance, meshlet) pair + global compaction
+    mcull_cull_result cull(const Globals &globals, const mcull_cull_params *params = nullptr) {
+        mcull_cull_result r{};
+        MCULL_CHECK(ctx_, mcull_cull(ctx_, &globals, params, &r));
+        return r;
+    }
+    uint64_t visibleCount() {
+        uint64_t n = 0;
+        MCULL_CHECK(ctx_, mcull_download_count(ctx_, &n));
+        return n;
+    }
+    std::vector<Visible> visibleList() {
+        std::vector<Visible> out(visibleCount());
+        uint64_t n = 0;
+        MCULL_CHECK(ctx_, mcull_download_list(ctx_, out.data(), out.size(), &n));
+        return out;
+    }
+    std::vector<DrawMeshTasksIndirectCommandNV> indirectCommands() {
+        std::vector<DrawMeshTasksIndirectCommandNV> out(instances_);
+        MCULL_CHECK(ctx_, mcull_download_commands(ctx_, out.data(), out.size() * sizeof(out[0])));
+        return out;
+    }
+    void waitIdle() { MCULL_CHECK(ctx_, mcull_synchronize(ctx_)); }
+    mcull_ctx *handle() const { return ctx_; }
+
+private:
+    mcull_ctx *ctx_ = nullptr;
+    uint64_t meshletCount_ = 0, instances_ = 0;
+};
+
+}  // namespace mcull

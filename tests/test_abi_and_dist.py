@@ -118,3 +118,30 @@ def test_two_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten):
         assert int(totals.sum()) == ref.total
     glob = np.concatenate([np.load(tmp_path / ("list_%d.npy" % r)) for r in range(world)])
     assert np.array_equal(glob, ref.list.view("<u4").reshape(-1, 2))
+
+
+def test_cpp_wrapper_compiles_and_throws_like_vk_check(tmp_path, mc):
+    """include/mcull.hpp: compiles as C++17 against the C ABI; without a GPU the constructor throws
+    std::runtime_error after printing to stderr (the reference's VK_CHECK behaviour, utils.hpp:68-79)."""
+    import subprocess
+
+    src = tmp_path / "t.cpp"
+    src.write_text(r"""
+#include "mcull.hpp"
+#include <cstdio>
+int main() {
+    std::printf("version %d\n", mcull_version());
+    try { mcull::Culler c(0); std::printf("created\n"); }
+    catch (const std::runtime_error &e) { std::printf("threw %s\n", e.what()); }
+    return 0;
+}""")
+    exe = tmp_path / "t"
+    lib_dir = os.path.dirname(mc.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-lmcull", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert "version %d" % mc.version() in out.stdout
+    if torch.cuda.is_available():
+        assert "created" in out.stdout
+    else:
+        assert "threw mcull error: MCULL_E_HIP" in out.stdout and "mcull error" in out.stderr
