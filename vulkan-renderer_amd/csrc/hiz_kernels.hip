@@ -16,6 +16,8 @@ namespace mcull {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 64;
+constexpr uint32_t kTicketGroups = 255;  // + 1 top counter = 1 KiB of ticket words
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y : x; }
 __device__ __forceinline__ float min4(float d0, float d1, float d2, float d3) {
@@ -59,6 +61,59 @@ __global__ __launch_bounds__(kBlock) void hiz_generic_kernel(const float *__rest
     }
 }
 
+// Levels base+1 .. base+4 of one 16x16 block of level `base` held in s2, through LDS (8x8, 4x4, 2x2, 1).
+// origin_x/y = level-0 coordinates of the block.  Child indices clamp to the last valid texel of the
+// source level inside the block (a no-op unless one image dimension has collapsed to 1).  With
+// WT_LAST the single texel of level base+4 is stored write-through at agent scope, because another
+// workgroup will read it in the same launch.
+template <bool WT_LAST>
+__device__ __forceinline__ void lds_levels(float (*s2)[17], float (*s3)[9], float (*s4)[5], float (*s5)[3],
+                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl, uint32_t levels,
+                                           uint32_t base, uint32_t origin_x, uint32_t origin_y, uint32_t t) {
+#define HIZ_LDS_LEVEL(STEP, SRC, DST, N, WT)                                                                    \
+    if (levels > base + (STEP)) {                                                                               \
+        const uint32_t K = base + (STEP);                                                                       \
+        if (t < (N) * (N)) {                                                                                    \
+            const uint32_t x = t % (N), y = t / (N);                                                            \
+            const uint32_t sw = tbl[K - 1], sh = tbl[16 + K - 1];                                               \
+            const uint32_t ox = origin_x >> (K - 1), oy = origin_y >> (K - 1);                                  \
+            const uint32_t mx = sw > ox ? min(sw - 1 - ox, 2u * (N)-1u) : 0u;                                   \
+            const uint32_t my = sh > oy ? min(sh - 1 - oy, 2u * (N)-1u) : 0u;                                   \
+            const uint32_t cx0 = min(2 * x, mx), cx1 = min(2 * x + 1, mx);                                      \
+            const uint32_t cy0 = min(2 * y, my), cy1 = min(2 * y + 1, my);                                      \
+            const float v = min4(SRC[cy0][cx0], SRC[cy0][cx1], SRC[cy1][cx0], SRC[cy1][cx1]);                   \
+            DST;                                                                                                \
+            const uint32_t lw = tbl[K], lh = tbl[16 + K];                                                       \
+            const uint32_t gx = (origin_x >> K) + x, gy = (origin_y >> K) + y;                                  \
+            if (gx < lw && gy < lh) {                                                                           \
+                float *dst = pyr + tbl[32 + K] + (size_t)gy * lw + gx;                                          \
+                if (WT) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 \
+                else *dst = v;                                                                                  \
+            }                                                                                                   \
+        }                                                                                                       \
+        __syncthreads();                                                                                        \
+    }
+    HIZ_LDS_LEVEL(1, s2, s3[y][x] = v, 8, false)
+    HIZ_LDS_LEVEL(2, s3, s4[y][x] = v, 4, false)
+    HIZ_LDS_LEVEL(3, s4, s5[y][x] = v, 2, false)
+    HIZ_LDS_LEVEL(4, s5, (void)0, 1, WT_LAST)
+#undef HIZ_LDS_LEVEL
+}
+
+// Stores an N x N register patch of level K whose top-left texel is (x0, y0).
+template <int N>
+__device__ __forceinline__ void store_patch(float *__restrict__ pyr, const uint32_t *__restrict__ tbl, uint32_t K,
+                                            uint32_t levels, uint32_t x0, uint32_t y0, const float *v) {
+    if (levels <= K) return;
+    const uint32_t lw = tbl[K], lh = tbl[16 + K];
+    float *dst = pyr + tbl[32 + K];
+#pragma unroll
+    for (int j = 0; j < N; j++)
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            if (x0 + i < lw && y0 + j < lh) dst[(size_t)(y0 + j) * lw + x0 + i] = v[j * N + i];
+}
+
 // Tiled kernel.  grid = (tiles_x, tiles_y), 256 threads, thread (tx,ty) = (t&15, t>>4) owns the
 // 4x4 level-0 patch at (tile_x0 + 4*tx, tile_y0 + 4*ty).  VEC: rows are 16-byte aligned (w % 4 == 0).
 template <bool VEC, bool SINGLE_PASS>
@@ -79,9 +134,10 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     for (int r = 0; r < 4; r++) {
         const uint32_t y = min(y0 + r, h - 1);
         if (VEC && x0 + 3 < w) {
-            const float4 q = *reinterpret_cast<const float4 *>(depth + (size_t)y * w + x0);
+            // the depth image is read once and level 0 is far larger than the caches: streaming hints
+            const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(depth + (size_t)y * w + x0));
             p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
-            if (y0 + r < h) *reinterpret_cast<float4 *>(pyr + (size_t)y * w + x0) = q;
+            if (y0 + r < h) __builtin_nontemporal_store(q, reinterpret_cast<f4v *>(pyr + (size_t)y * w + x0));
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -125,46 +181,26 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     s2[ty][tx] = q2;
     __syncthreads();
 
-    // ---- levels 3..6 through LDS.  Child indices clamp to the last valid texel of the source
-    // level inside this tile (a no-op unless one image dimension has collapsed to 1).
-    const uint32_t tile_x = blockIdx.x * kTile, tile_y = blockIdx.y * kTile;
-#define HIZ_LDS_LEVEL(K, SRC, DST, N)                                                                           \
-    if (levels > (K)) {                                                                                         \
-        if (t < (N) * (N)) {                                                                                    \
-            const uint32_t x = t % (N), y = t / (N);                                                            \
-            const uint32_t sw = tbl[(K)-1], sh = tbl[16 + (K)-1];                                               \
-            const uint32_t ox = tile_x >> ((K)-1), oy = tile_y >> ((K)-1);                                      \
-            const uint32_t mx = sw > ox ? min(sw - 1 - ox, 2u * (N)-1u) : 0u;                                   \
-            const uint32_t my = sh > oy ? min(sh - 1 - oy, 2u * (N)-1u) : 0u;                                   \
-            const uint32_t cx0 = min(2 * x, mx), cx1 = min(2 * x + 1, mx);                                      \
-            const uint32_t cy0 = min(2 * y, my), cy1 = min(2 * y + 1, my);                                      \
-            const float v = min4(SRC[cy0][cx0], SRC[cy0][cx1], SRC[cy1][cx0], SRC[cy1][cx1]);                   \
-            DST;                                                                                                \
-            const uint32_t lw = tbl[(K)], lh = tbl[16 + (K)];                                                   \
-            const uint32_t gx = (tile_x >> (K)) + x, gy = (tile_y >> (K)) + y;                                  \
-            if (gx < lw && gy < lh) pyr[tbl[32 + (K)] + (size_t)gy * lw + gx] = v;                              \
-        }                                                                                                       \
-        __syncthreads();                                                                                        \
-    }
-    HIZ_LDS_LEVEL(3, s2, s3[y][x] = v, 8)
-    HIZ_LDS_LEVEL(4, s3, s4[y][x] = v, 4)
-    HIZ_LDS_LEVEL(5, s4, s5[y][x] = v, 2)
-    HIZ_LDS_LEVEL(6, s5, (void)0, 1)
-#undef HIZ_LDS_LEVEL
+    // ---- levels 3..6 through LDS
+    lds_levels<SINGLE_PASS>(s2, s3, s4, s5, pyr, tbl, levels, 2u, blockIdx.x * kTile, blockIdx.y * kTile, t);
 
     if (!SINGLE_PASS || levels <= 7) return;
 
-    // ---- levels 7..: done by the workgroup that arrives last.  Hand-off of the level-6 texels:
-    // every storing wave drains its stores, the workgroup barrier orders them before lane 0's
-    // agent-scope release, the ticket is taken after the release; the last arriver acquires at
-    // agent scope (one lane), then the barrier lets the other waves read with plain loads.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- levels 7..: done by the workgroup that arrives last.  Each workgroup produced exactly one
+    // level-6 texel, written by thread 0 with a write-through (agent-scope) store; thread 0 drains
+    // that store and then takes a ticket.  No L2 write-back is needed on the producer side.  The
+    // last arriver acquires at agent scope (one lane), the barrier releases the other waves.
+    // Tickets are two-level (up to kTicketGroups group counters + one top counter): a single word
+    // sustains only ~90 returning atomics per microsecond, which 16 384 workgroups would queue on.
     if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == gridDim.x * gridDim.y - 1u) ? 1u : 0u;
+        const uint32_t n_wg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t n_grp = n_wg < kTicketGroups ? n_wg : kTicketGroups;
+        const uint32_t grp = lin % n_grp, members = (n_wg - grp + n_grp - 1u) / n_grp;
+        uint32_t last = 0u;
+        if (__hip_atomic_fetch_add(counter + 1u + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)
+            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_grp - 1u;
+        s_last = last;
     }
     __syncthreads();
     if (s_last == 0u) return;
@@ -173,7 +209,57 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    reduce_levels_from_global(pyr, tbl, 7, levels);
+    // every ticket of this launch has been taken: leave the words zero for the next launch on the
+    // stream (they are zeroed once at allocation; no per-call memset is needed)
+    if (t <= kTicketGroups) counter[t] = 0u;
+    const uint32_t w6 = tbl[6], h6 = tbl[16 + 6];
+    if (w6 > 128u || h6 > 128u) {  // images beyond 8192 texels a side: level by level from memory
+        reduce_levels_from_global(pyr, tbl, 7, levels);
+        return;
+    }
+    // Thread (tx,ty) owns the 8x8 patch of level 6 at (8*tx, 8*ty): levels 7-9 in registers, then the
+    // 16x16 level-9 values go through the same LDS ladder for levels 10-13.  A child index beyond the
+    // source extent can only occur when that extent is 1; it then clamps to texel 0.
+    {
+        const float *l6 = pyr + tbl[32 + 6];
+        float q[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t y = min(8 * ty + r, h6 - 1);
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t x = min(8 * tx + c, w6 - 1);
+                q[r][c] = l6[(size_t)y * w6 + x];
+            }
+        }
+        const bool cx6 = (w6 == 1u), cy6 = (h6 == 1u);
+        float q7[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x1 = cx6 ? 2 * i : 2 * i + 1, y1 = cy6 ? 2 * j : 2 * j + 1;
+                q7[j][i] = min4(q[2 * j][2 * i], q[2 * j][x1], q[y1][2 * i], q[y1][x1]);
+            }
+        store_patch<4>(pyr, tbl, 7, levels, 4 * tx, 4 * ty, &q7[0][0]);
+        const bool cx7 = (tbl[7] == 1u), cy7 = (tbl[16 + 7] == 1u);
+        float q8[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int x1 = cx7 ? 2 * i : 2 * i + 1, y1 = cy7 ? 2 * j : 2 * j + 1;
+                q8[j][i] = min4(q7[2 * j][2 * i], q7[2 * j][x1], q7[y1][2 * i], q7[y1][x1]);
+            }
+        store_patch<2>(pyr, tbl, 8, levels, 2 * tx, 2 * ty, &q8[0][0]);
+        const bool cx8 = levels > 8 && tbl[8] == 1u, cy8 = levels > 8 && tbl[16 + 8] == 1u;
+        const float q9 = min4(q8[0][0], q8[0][cx8 ? 0 : 1], q8[cy8 ? 0 : 1][0], q8[cy8 ? 0 : 1][cx8 ? 0 : 1]);
+        store_patch<1>(pyr, tbl, 9, levels, tx, ty, &q9);
+        __syncthreads();  // s2 is free again: every wave has finished the tile's LDS ladder
+        s2[ty][tx] = q9;
+        __syncthreads();
+        lds_levels<false>(s2, s3, s4, s5, pyr, tbl, levels, 9u, 0u, 0u, t);
+    }
 }
 
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
@@ -187,8 +273,6 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
                      (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u;
     if (single_pass && levels > 7) {
-        hipError_t e = hipMemsetAsync(counter, 0, 256, st);
-        if (e != hipSuccess) return e;
         if (vec)
             hipLaunchKernelGGL((hiz_tile_kernel<true, true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
                                level_table, levels, counter);
