@@ -213,3 +213,28 @@ def synthetic_transforms(n_instances, extent=50.0, seed=43):
     out = np.zeros(n_instances, dtype=TRANSFORM)
     out["model"] = m.reshape(n_instances, 16)
     return out
+
+
+def proxy_mesh(nu, nv, seed=1, bumps=6.0):
+    """Procedural closed surface (a bumpy torus) with 2*nu*nv triangles: the stand-in for the
+    reference's dragon.obj / buddha.obj, which are missing from the reference snapshot.  It is NOT
+    one of the Stanford scans; only the triangle count is matched (660x660 -> 871 200 triangles,
+    680x800 -> 1 088 000).  Returns (positions float32 (n,3), triangle vertex ids int32 (t,3))."""
+    rs = np.random.RandomState(seed)
+    ph = rs.uniform(0, 2 * np.pi, 3)
+    u = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    v = np.linspace(0, 2 * np.pi, nv, endpoint=False)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    r = 0.35 + 0.05 * np.sin(bumps * U + ph[0]) * np.cos((bumps + 1) * V + ph[1]) + 0.02 * np.sin(17 * U + 3 * V + ph[2])
+    x = (1 + r * np.cos(V)) * np.cos(U)
+    y = (1 + r * np.cos(V)) * np.sin(U)
+    z = r * np.sin(V)
+    pos = np.stack([x, y, z], -1).reshape(-1, 3).astype(f32)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    a = i * nv + j
+    b = ((i + 1) % nu) * nv + j
+    c = i * nv + (j + 1) % nv
+    d = ((i + 1) % nu) * nv + (j + 1) % nv
+    tris = np.stack([np.stack([a, b, c], -1), np.stack([b, d, c], -1)], 2).reshape(-1, 3).astype(np.int32)
+    return pos, tris
