@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
     ap.add_argument("--hiz", action="store_true", help="also run the Hi-Z test against a 4K pyramid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,9 +84,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
@@ -108,22 +112,42 @@ def main():
         ctx.hiz_build(depth.data_ptr(), view=0, width=3840, height=2160, mem=mc.MEM_DEVICE)
         tests |= mc.TEST_HIZ
 
-    # caller-owned outputs (torch owns what the collectives touch)
+    # caller-owned outputs (torch owns what the collectives touch); commands and counts are double
+    # buffered so that the gather of step k overlaps the cull of step k+1
     lst = torch.empty((n_pairs, 2), device=device, dtype=torch.int32)
-    cmds = torch.zeros((n_inst, 2), device=device, dtype=torch.int32)
-    total = torch.zeros(1, device=device, dtype=torch.int64)
+    cmds = [torch.zeros((n_inst, 2), device=device, dtype=torch.int32) for _ in range(2)]
+    total = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(2)]
     kernel_ms = []
+    gathered = [None, None]
+    if multi:
+        comm = torch.cuda.Stream(device=device)
+        ev_cull = [torch.cuda.Event() for _ in range(2)]
+        ev_comm = [torch.cuda.Event() for _ in range(2)]
+        main = torch.cuda.current_stream(device)
 
-    def step(record):
+    def step(k, record=False):
+        b = k & 1
+        if multi:
+            main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
         ctx.cull(g, tests=tests, compaction=args.compaction, list_ptr=lst.data_ptr(), list_capacity=n_pairs,
-                 commands_ptr=cmds.data_ptr(), total_ptr=total.data_ptr())
-        if world > 1:
-            mdist.gather_draw_list(total, cmds, lambda totals, rk: ctx.rebase_commands(totals.data_ptr(), rk))
+                 commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+        if multi:
+            # per-rank counts -> every rank's list offset -> rebased per-instance commands, gathered
+            # into one global draw-list description; runs on a side stream beside the next cull
+            ev_cull[b].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_cull[b])
+
+                def rebase(totals_all, rk, cb=cmds[b]):
+                    cb[:, 1] += totals_all[:rk].sum().to(torch.int32)
+
+                gathered[b] = mdist.gather_draw_list(total[b], cmds[b], rebase)
+                ev_comm[b].record(comm)
         if record:
             kernel_ms.append(ctx.last_kernel_ms())
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -133,28 +157,34 @@ def main():
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
     assert hip.hipEventCreate(ctypes.byref(ev0)) == 0 and hip.hipEventCreate(ctypes.byref(ev1)) == 0
 
-    for _ in range(args.warmup):
-        step(False)
+    for k in range(args.warmup):
+        step(k)
     fence()
     t0 = time.perf_counter()
     assert hip.hipEventRecord(ev0, None) == 0
-    for _ in range(args.steps):
-        step(False)
+    for k in range(args.steps):
+        step(k)
     assert hip.hipEventRecord(ev1, None) == 0
     fence()
     elapsed = time.perf_counter() - t0
     dev_ms = ctypes.c_float()
     assert hip.hipEventElapsedTime(ctypes.byref(dev_ms), ev0, ev1) == 0
     region_ms_per_step = dev_ms.value / args.steps
-    if world > 1:
+    if multi:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
-    for _ in range(min(args.steps, 10)):
-        step(True)
-    visible = int(total.item())
+    for k in range(min(args.steps, 10)):
+        step(k, record=True)
+    fence()
+    visible = int(total[0].item())
+    if multi:  # the gathered description must be consistent on every rank
+        totals_all, cmds_all = gathered[0]
+        assert totals_all.numel() == world and cmds_all.shape[0] == world * n_inst
+        mine = cmds_all[rank * n_inst:(rank + 1) * n_inst].to(torch.int64)
+        assert int(mine[:, 0].sum()) == int(totals_all[rank]) and int(mine[0, 1]) == int(totals_all[:rank].sum())
     ms_per_step = elapsed / args.steps * 1e3
     value = n_pairs * world / (elapsed / args.steps) / 1e9
 
@@ -173,7 +203,8 @@ def main():
                             "frustum+cone%s, %s compaction" % (n_inst, per, n_pairs, "+hiz(4K)" if args.hiz else "",
                                                                ["ordered", "wave-atomic", "block-atomic"][args.compaction]),
                 "meshlet_instances_per_gpu": n_pairs, "visible_fraction": round(visible / n_pairs, 4),
-                "parallelism": "instances sharded x%d, RCCL all-gather of counts+commands" % world if world > 1 else "single GPU",
+                "parallelism": ("instances sharded x%d, RCCL all-gather of counts + rebased commands overlapped with the next cull" % world)
+                if multi else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -187,7 +218,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cone, sphere, xf, off, cnt, g, tests, n_inst, per)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

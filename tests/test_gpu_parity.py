@@ -226,3 +226,27 @@ def test_errors(mc, ctx, kitten, config1):
         ctx.download_list()
     assert e.value.status == mc.E_CAPACITY
     assert ctx.download_count() > 1000
+
+
+def test_rebase_commands(mc, O, ctx, kitten, config1):
+    """mcull_rebase_commands: firstTask += sum of the lower ranks' visible counts, read from a device
+    array of gathered totals (the multi-GPU hand-off); taskCount unchanged; idempotent per call."""
+    import torch
+
+    g, t = config1["globals"], config1["transforms"]
+    ref = O.cull_scene(O.View(g), t, kitten["meshlets"], tests=3)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    totals = torch.tensor([5, 7, 11, 13], dtype=torch.int64, device="cuda")
+    for compaction in (0, 1):
+        ctx.cull(g, tests=3, compaction=compaction)
+        for rank, base in ((0, 0), (2, 12), (3, 23), (2, 12)):
+            ctx.rebase_commands(totals.data_ptr(), rank)
+            cmds = ctx.download_commands(len(t)).view(mc.CMD)
+            assert np.array_equal(cmds["taskCount"], ref.commands["taskCount"])
+            want = ref.commands["firstTask"] + base if compaction == 0 else np.full(len(t), base, dtype="<u4")
+            assert np.array_equal(cmds["firstTask"], want)
+    # the ordered cull after the rebases still starts from clean tile counters
+    ctx.cull(g, tests=3)
+    assert ctx.download_list().tobytes() == ref.list.tobytes()
