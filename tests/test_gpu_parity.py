@@ -208,14 +208,14 @@ def test_bounds_bit_exact(mc, O, ctx, kitten, bunny):
         assert got.tobytes() == ref.tobytes()
 
 
-def test_errors(mc, ctx, kitten, config1):
+def test_errors(mc, kitten, config1):
     g, t = config1["globals"], config1["transforms"]
-    ctx.set_instance_ranges(None, None)
+    ctx = mc.Context(0)  # a fresh context: no pyramids, no ranges
     ctx.upload_meshlets(kitten["meshlets"])
     ctx.upload_transforms(t)
     bad = g.copy(); bad["meshletCount"] = 10 ** 6
     with pytest.raises(mc.McullError) as e:
-        ctx.cull(bad)
+        ctx.cull(bad, tests=3)
     assert e.value.status == mc.E_INVALID
     with pytest.raises(mc.McullError) as e:
         ctx.cull(g, tests=7, hiz_view=7)
@@ -226,6 +226,7 @@ def test_errors(mc, ctx, kitten, config1):
         ctx.download_list()
     assert e.value.status == mc.E_CAPACITY
     assert ctx.download_count() > 1000
+    ctx.close()
 
 
 def test_rebase_commands(mc, O, ctx, kitten, config1):

@@ -1,5 +1,6 @@
-// Access-pattern experiments for the cull kernel (not part of the product): how fast can the two
-// SoA bounds streams be consumed under different group->wave assignments?  Build + run:
+// Design-evidence benchmark for the cull + compact kernels (not part of the product): the product
+// kernels against variants that make the other choice (AoS records, LDS-staged transforms, plain
+// loads/stores, atomic compaction) on the 100 M meshlet-instance scene.  Build + run:
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I. tools/bench_patterns.hip -o tools/bench_patterns
 #include <cstdio>
 #include <cstdlib>
@@ -11,52 +12,69 @@
 
 using namespace mcull;
 
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load(const float4 *p) {
-    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
-    return make_float4(q.x, q.y, q.z, q.w);
-}
-
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-// B: persistent, globally strided: iteration k of block b, wave w -> group (k*P + b)*4 + w
-template <uint32_t TESTS, int DEPTH>
-__global__ __launch_bounds__(kBlock) void cull_strided_kernel(const float4 *__restrict__ cone_axis_w,
-                                                              const float4 *__restrict__ centre_radius,
-                                                              const float4 *__restrict__ transforms,
-                                                              const uint4 *__restrict__ group_rec,
-                                                              uint32_t groups_per_instance, uint32_t n_groups,
-                                                              ViewConst v, uint64_t *__restrict__ mask) {
+// Variant: bounds read from the reference's 48-byte AoS records instead of the two SoA streams.
+template <uint32_t TESTS, int NG>
+__global__ __launch_bounds__(kBlock) void cull_aos_kernel(const mcull_meshlet *__restrict__ aos,
+                                                          const float4 *__restrict__ transforms,
+                                                          const float *__restrict__ xf_scale,
+                                                          const uint4 *__restrict__ group_rec, uint32_t n_groups, ViewConst v,
+                                                          uint64_t *__restrict__ mask) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t stride = gridDim.x * kWaves;
-    uint32_t g = blockIdx.x * kWaves + wave;
-    GroupInfo gi = {0, 0, 0, 0};
-    Xform m = {};
-    float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
-    if (g < n_groups) {
-        gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
-        m = load_xform(transforms, gi.inst);
-        if (lane < gi.count) { a = cone_axis_w[gi.first_meshlet + lane]; c = centre_radius[gi.first_meshlet + lane]; }
+    const uint32_t g0 = blockIdx.x * (kWaves * NG) + wave * NG;
+    GroupInfo gi[NG]; Xform m[NG]; float scale[NG]; float4 a[NG], c[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        gi[k] = group_lookup(min(g0 + k, n_groups - 1u), group_rec, 0u, 0u);
+        if (g0 + k >= n_groups) gi[k].count = 0;
+        m[k] = load_xform(transforms, gi[k].inst);
+        scale[k] = xf_scale[gi[k].inst];
+        const float4 *rec = reinterpret_cast<const float4 *>(aos + gi[k].first_meshlet + lane);
+        const float4 cone = rec[0], apex = rec[1], tail = rec[2];
+        a[k] = cone; c[k] = make_float4(apex.x, apex.y, apex.z, tail.x);
     }
-    while (g < n_groups) {
-        const uint32_t gn = g + stride;
-        GroupInfo gin = {0, 0, 0, 0};
-        Xform mn = {};
-        float4 an = make_float4(0, 0, 0, 0), cn = make_float4(0, 0, 0, 0);
-        if (gn < n_groups) {
-            gin = group_lookup(gn, group_rec, groups_per_instance, v.uniform_count);
-            mn = load_xform(transforms, gin.inst);
-            if (lane < gin.count) { an = cone_axis_w[gin.first_meshlet + lane]; cn = centre_radius[gin.first_meshlet + lane]; }
-        }
-        const bool vis = (lane < gi.count) && pair_visible<TESTS>(v, m, xform_scale(m.c0), a, c);
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
         const uint64_t ballot = __ballot(vis);
-        if (lane == 0) mask[g] = ballot;
-        g = gn; gi = gin; m = mn; a = an; c = cn;
+        if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
     }
 }
 
-// D: read floor: same two streams, trivial arithmetic (sum of .w), strided or tile walk
+// Variant: instance transforms fetched per wave with wave-uniform scalar loads into SGPRs (the
+// product stages them in LDS with one coalesced load per workgroup).
+template <uint32_t TESTS, int NG, bool NT>
+__global__ __launch_bounds__(kBlock) void cull_sgpr_xform_kernel(const float4 *__restrict__ cone_axis_w,
+                                                                 const float4 *__restrict__ centre_radius,
+                                                                 const float4 *__restrict__ transforms,
+                                                                 const float *__restrict__ xf_scale,
+                                                                 const uint4 *__restrict__ group_rec, uint32_t n_groups,
+                                                                 ViewConst v, uint64_t *__restrict__ mask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g0 = blockIdx.x * (kWaves * NG) + wave * NG;
+    GroupInfo gi[NG]; Xform m[NG]; float scale[NG]; float4 a[NG], c[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        gi[k] = group_lookup(min(g0 + k, n_groups - 1u), group_rec, 0u, 0u);
+        if (g0 + k >= n_groups) gi[k].count = 0;
+        m[k] = load_xform(transforms, gi[k].inst);
+        scale[k] = xf_scale[gi[k].inst];
+        const uint32_t last = gi[k].count ? gi[k].count - 1u : 0u;
+        const uint32_t id = gi[k].first_meshlet + (lane < last ? lane : last);
+        a[k] = load_bounds<NT>(cone_axis_w + id);
+        c[k] = load_bounds<NT>(centre_radius + id);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
+        const uint64_t ballot = __ballot(vis);
+        if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
+    }
+}
+
 template <bool STRIDED, int UNROLL, bool NT>
 __global__ __launch_bounds__(kBlock) void read_floor_kernel(const float4 *__restrict__ cone_axis_w,
                                                             const float4 *__restrict__ centre_radius, uint32_t n_groups,
@@ -71,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void read_floor_kernel(const float4 *__rest
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t gg = min(g + u * step, g_end - 1);
-            if (NT) { a[u] = nt_load(&cone_axis_w[(size_t)gg * 64 + lane]); c[u] = nt_load(&centre_radius[(size_t)gg * 64 + lane]); }
-            else { a[u] = cone_axis_w[(size_t)gg * 64 + lane]; c[u] = centre_radius[(size_t)gg * 64 + lane]; }
+            a[u] = load_bounds<NT>(&cone_axis_w[(size_t)gg * 64 + lane]);
+            c[u] = load_bounds<NT>(&centre_radius[(size_t)gg * 64 + lane]);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -91,6 +109,14 @@ __global__ __launch_bounds__(256) void write_kernel(unsigned long long *out, siz
         if (NT) __builtin_nontemporal_store((unsigned long long)i, out + i);
         else out[i] = i;
     }
+}
+
+__global__ void fill_aos_kernel(const float4 *cone, const float4 *sphere, mcull_meshlet *aos, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = cone[i], c = sphere[i];
+    aos[i].cone[0] = a.x; aos[i].cone[1] = a.y; aos[i].cone[2] = a.z; aos[i].cone[3] = a.w;
+    aos[i].coneApex[0] = c.x; aos[i].coneApex[1] = c.y; aos[i].coneApex[2] = c.z; aos[i].radius = c.w;
 }
 
 int main(int argc, char **argv) {
@@ -165,14 +191,54 @@ int main(int argc, char **argv) {
         printf("%-44s avg %.1f us  best %.1f us  (%.2f TB/s of bounds)\n", name, sum * 100, best * 1000, n * 32 / (sum / 10 * 1e-3) / 1e12);
     };
     const uint32_t tiles = (n_groups + 255) / 256;
-    uint32_t *sc; CK(hipMalloc(&sc, 1 << 16)); CK(hipMemset(tc, 0, 1 << 20)); CK(hipMemset(sc, 0, 1 << 16));
+    (void)tiles;
+    CK(hipMemset(tc, 0, 1 << 20));
+    printf("-- cull pass (mask only): group assignment, streaming hint, requests in flight\n");
 #define PRODUCT(NG, NT) timeit("product cull_mask_kernel<3," #NG "," #NT ">", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, NG, NT>), dim3((n_groups + 4 * NG - 1) / (4 * NG)), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc); });
-    PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(3, true) PRODUCT(4, false) PRODUCT(4, true)
+    PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(4, false) PRODUCT(4, true)
     {
         std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
         uint64_t vis = 0; for (auto w : hm) vis += __builtin_popcountll(w);
         printf("visible fraction %.3f\n", (double)vis / n);
     }
+    printf("-- layout: the reference's 48-byte AoS records vs two SoA float4 streams\n");
+    {
+        mcull_meshlet *aos; CK(hipMalloc(&aos, n * sizeof(mcull_meshlet)));
+        CK(hipMemset(aos, 0, n * sizeof(mcull_meshlet)));
+        // fill the AoS records from the SoA streams on the device
+        hipLaunchKernelGGL(fill_aos_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, cone, sphere, aos, n);
+        CK(hipDeviceSynchronize());
+        timeit("cull_aos_kernel<3,4> (48-byte AoS records)", [&] { hipLaunchKernelGGL((cull_aos_kernel<3, 4>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, aos, xf, scale, rec, n_groups, v, mask); });
+        CK(hipFree(aos));
+    }
+    printf("-- instance transforms: staged in LDS (product) vs scalar loads into SGPRs\n");
+    timeit("cull_sgpr_xform_kernel<3,4,true> (SGPR transforms)", [&] { hipLaunchKernelGGL((cull_sgpr_xform_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, n_groups, v, mask); });
+    PRODUCT(4, true)
+    printf("-- read floor of the two bounds streams (trivial arithmetic)\n");
+    timeit("read floor, plain loads", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    timeit("read floor, non-temporal loads", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
+    printf("-- compaction: ordered (mask + tile counters + scatter) vs one atomic per wavefront / per workgroup\n");
+    {
+        mcull_visible *list; const uint64_t cap = n; CK(hipMalloc(&list, cap * 8));
+        uint32_t *inst_first, *inst_count; unsigned long long *total;
+        CK(hipMalloc(&inst_first, (size_t)(n_inst + 1) * 4)); CK(hipMalloc(&inst_count, (size_t)(n_inst + 1) * 4)); CK(hipMalloc(&total, 256));
+        CK(hipMemset(tc, 0, 1 << 20));
+        auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
+        timeit("ordered: cull_mask<3,4,nt> + compact<nt> + counter reset", [&] {
+            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
+            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total);
+            zero_tc();
+        });
+        timeit("single pass: one atomic per wavefront", [&] {
+            CK(hipMemsetAsync(total, 0, 8)); CK(hipMemsetAsync(inst_count, 0, (size_t)(n_inst + 1) * 4));
+            hipLaunchKernelGGL((cull_atomic_kernel<3, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, list, cap, inst_count, total, (uint64_t *)nullptr);
+        });
+        timeit("single pass: one atomic per workgroup step", [&] {
+            CK(hipMemsetAsync(total, 0, 8)); CK(hipMemsetAsync(inst_count, 0, (size_t)(n_inst + 1) * 4));
+            hipLaunchKernelGGL((cull_atomic_kernel<3, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, list, cap, inst_count, total, (uint64_t *)nullptr);
+        });
+    }
+    printf("-- list stores: plain vs non-temporal, effect on the following cull pass\n");
     {
         unsigned long long *wbuf; const size_t n8 = 51400000; CK(hipMalloc(&wbuf, n8 * 8));
         hipEvent_t ev[64]; for (auto &e : ev) CK(hipEventCreate(&e));
@@ -180,7 +246,7 @@ int main(int argc, char **argv) {
             for (int rep = 0; rep < 2; rep++) {
                 for (int i = 0; i < 10; i++) {
                     CK(hipEventRecord(ev[3 * i]));
-                    hipLaunchKernelGGL((cull_mask_kernel<3, 2, true>), dim3((n_groups + 7) / 8), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
+                    hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
                     CK(hipEventRecord(ev[3 * i + 1]));
                     if (nt) hipLaunchKernelGGL(write_kernel<true>, dim3(2048), dim3(256), 0, 0, wbuf, n8);
                     else hipLaunchKernelGGL(write_kernel<false>, dim3(2048), dim3(256), 0, 0, wbuf, n8);
@@ -195,23 +261,8 @@ int main(int argc, char **argv) {
                 CK(hipEventElapsedTime(&ms, ev[3 * i + 1], ev[3 * i + 2])); wr += ms;
             }
             CK(hipEventElapsedTime(&tot, ev[0], ev[30]));
-            printf("alternating K1 / 411 MB %s write: K1 %.1f us, write %.1f us, pair %.1f us\n", nt ? "nt" : "plain", k1 * 100, wr * 100, tot * 100);
+            printf("alternating cull / 411 MB %s write: cull %.1f us, write %.1f us, pair %.1f us\n", nt ? "non-temporal" : "plain", k1 * 100, wr * 100, tot * 100);
         }
-    }
-    for (int bpc : {6, 12}) {
-        char nm[64]; snprintf(nm, sizeof nm, "B strided persistent, %d blocks/CU", bpc);
-        timeit(nm, [&] { hipLaunchKernelGGL((cull_strided_kernel<3, 1>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, xf, rec, 0u, n_groups, v, mask); });
-    }
-    timeit("D read floor, tile walk u1", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 1, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-    timeit("D read floor, tile walk u2", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 2, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-    timeit("D read floor, tile walk u4", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-    timeit("D read floor, tile walk u4 nt", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 4, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-    timeit("D read floor, tile walk u1 nt", [&] { hipLaunchKernelGGL((read_floor_kernel<false, 1, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-    for (int bpc : {4, 8})  {
-        char nm[64]; snprintf(nm, sizeof nm, "D read floor, strided u1, %d blocks/CU", bpc);
-        timeit(nm, [&] { hipLaunchKernelGGL((read_floor_kernel<true, 1, false>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
-        snprintf(nm, sizeof nm, "D read floor, strided u4 nt, %d blocks/CU", bpc);
-        timeit(nm, [&] { hipLaunchKernelGGL((read_floor_kernel<true, 4, true>), dim3(256 * bpc), dim3(256), 0, 0, cone, sphere, n_groups, mask); });
     }
     return 0;
 }

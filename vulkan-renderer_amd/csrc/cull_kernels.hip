@@ -163,45 +163,60 @@ __device__ __forceinline__ void store_entry(mcull_visible *__restrict__ list, un
 
 // ------------------------------------------------------------------------------------------------
 // ordered, pass 1: visibility ballots.  Small workgroups: each of the 4 waves takes NG consecutive
-// groups, requests all their bounds up front (NG x 2 KiB in flight per wave), evaluates them and
-// stores NG ballot words.  The workgroup's visible count is added to its 256-group tile's counter
-// (one atomic per workgroup, 256/(4*NG) per counter; the counters are zero on entry and re-zeroed
-// by emit_commands_kernel).
+// groups.  The workgroup first stages the 4*NG group records in LDS, then requests every group's
+// bounds (all loads unconditional and up front: NG x 2 KiB in flight per wave) while one wave
+// stages the instance transforms in LDS with a coalesced load; after the barrier each wave reads
+// its transforms back as LDS broadcasts, evaluates its groups and stores NG ballot words.  The
+// workgroup's visible count is added to its 256-group tile's counter (one atomic per workgroup,
+// 256/(4*NG) per counter; the counters are zero on entry and re-zeroed by emit_commands_kernel).
+// Staging the transforms in LDS measured 3-6 % faster than wave-uniform scalar loads into SGPRs,
+// whose dependent record -> transform chain stalls every wave on its own.
 template <uint32_t TESTS, int NG, bool NT>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
     uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts) {
+    constexpr uint32_t kGroups = kWaves * NG;  // groups per workgroup
+    __shared__ uint4 s_rec[kGroups];
+    __shared__ float4 s_x[kGroups][4];
+    __shared__ float s_scale[kGroups];
     __shared__ uint32_t s_count[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t block_g0 = blockIdx.x * (kWaves * NG);
-    const uint32_t g0 = block_g0 + wave * NG;
-    GroupInfo gi[NG];
-    Xform m[NG];
-    float scale[NG];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block_g0 = blockIdx.x * kGroups;
+    if (threadIdx.x < kGroups) {
+        const uint32_t g = block_g0 + threadIdx.x;
+        GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, v.uniform_count);
+        if (g >= n_groups) gi.count = 0;  // out-of-range groups re-read a valid element and report nothing
+        s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
+    }
+    __syncthreads();
+    if (threadIdx.x < kGroups * 4) {
+        const uint32_t k = threadIdx.x >> 2, j = threadIdx.x & 3u;
+        s_x[k][j] = transforms[(size_t)s_rec[k].x * 4 + j];
+        if (j == 0) s_scale[k] = xf_scale[s_rec[k].x];
+    }
     float4 a[NG], c[NG];
-    // All loads are unconditional (out-of-range groups and lanes re-read a valid element) so that
-    // the 2*NG bounds requests of a wave are issued back to back before the first wait.
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const bool valid = g0 + k < n_groups;
-        gi[k] = group_lookup(valid ? g0 + k : n_groups - 1u, group_rec, groups_per_instance, v.uniform_count);
-        if (!valid) gi[k].count = 0;
-        m[k] = load_xform(transforms, gi[k].inst);
-        scale[k] = xf_scale[gi[k].inst];
-        const uint32_t last = gi[k].count ? gi[k].count - 1u : 0u;
-        const uint32_t id = gi[k].first_meshlet + (lane < last ? lane : last);
+        const uint4 r = s_rec[wave * NG + k];
+        const uint32_t last = r.z ? r.z - 1u : 0u;
+        const uint32_t id = r.y + (lane < last ? lane : last);
         a[k] = load_bounds<NT>(cone_axis_w + id);
         c[k] = load_bounds<NT>(centre_radius + id);
     }
+    __syncthreads();
     uint32_t count = 0;
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
+        const uint32_t slot = wave * NG + k;
+        Xform m;
+        m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
+        const uint32_t n_valid = s_rec[slot].z;
+        const bool vis = pair_visible<TESTS>(v, m, s_scale[slot], a[k], c[k]) && (lane < n_valid);
         const uint64_t ballot = __ballot(vis);
-        if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
+        if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
         count += (uint32_t)__popcll(ballot);
     }
     if (lane == 0) s_count[wave] = count;

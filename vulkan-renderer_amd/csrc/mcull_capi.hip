@@ -54,6 +54,7 @@ struct mcull_ctx {
 
     // cull scratch + outputs
     DevBuf mask, tile_counts, super_counts, inst_first, inst_count, total, list, commands;
+    uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
     bool counters_clean = false;  // tile/super counters are all zero (K1 adds into them, K4 re-zeroes)
     uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
     // description of the last cull (for rebase / downloads / payloads)
@@ -566,10 +567,13 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     void *commands = p.commands;
     if (!commands) {
         const size_t bytes = (size_t)c->n_instances * p.cmd_stride;
-        const bool fresh = !c->commands.p || c->commands.cap < bytes;
+        // bytes of a record outside the 8-byte command are never written by the kernels: the
+        // context-owned buffer is zeroed whenever it is (re)allocated or its record layout changes
+        const uint64_t layout_key = ((uint64_t)p.cmd_stride << 32) | p.cmd_offset;
+        const bool fresh = !c->commands.p || c->commands.cap < bytes || c->commands_layout != layout_key;
         if ((rc = ensure(c, c->commands, bytes))) return rc;
-        // bytes of a record outside the 8-byte command are never written by the kernels
         if (fresh) HIPCHK(c, hipMemsetAsync(c->commands.p, 0, c->commands.cap, c->stream));
+        c->commands_layout = layout_key;
         commands = c->commands.p;
     }
     const uint32_t n_tiles = mcull::tile_count_for(s.n_groups);
