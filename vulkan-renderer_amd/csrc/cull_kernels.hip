@@ -169,8 +169,9 @@ __device__ __forceinline__ void store_entry(mcull_visible *__restrict__ list, un
 // its transforms back as LDS broadcasts, evaluates its groups and stores NG ballot words.  The
 // workgroup's visible count is added to its 256-group tile's counter (one atomic per workgroup,
 // 256/(4*NG) per counter; the counters are zero on entry and re-zeroed by emit_commands_kernel).
-// Staging the transforms in LDS measured 3-6 % faster than wave-uniform scalar loads into SGPRs,
-// whose dependent record -> transform chain stalls every wave on its own.
+// Staging the transforms in LDS and fetching them with wave-uniform scalar loads into SGPRs
+// measured the same within run-to-run noise (about 480 us for 100 M pairs); LDS staging keeps the
+// SGPR budget small and replaces 4*NG dependent scalar load chains by one coalesced vector load.
 template <uint32_t TESTS, int NG, bool NT>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
