@@ -166,6 +166,23 @@ def test_hiz_pyramid_bit_exact(mc, O, ctx, shape):
         assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "level %d differs" % k
 
 
+@pytest.mark.parametrize("shape", [(1080, 1920), (2160, 3840)])
+def test_hiz_rebuild_same_buffer_sees_no_stale_texels(mc, O, ctx, shape):
+    """Rebuilding into the same pyramid with different depth must not pick up the previous build's
+    level-6/level-9 texels from any cache: those are the texels one workgroup hands to another."""
+    h, w = shape
+    rs = np.random.RandomState(5)
+    a = rs.uniform(0, 1, (h, w)).astype("<f4")
+    depths = [a, (1.0 - a).astype("<f4"), np.roll(a, 97, axis=1).copy(), a]
+    for depth in depths:
+        ref = O.hiz_levels(O.hiz_build(depth), w, h)
+        ctx.hiz_build(depth, view=2)
+        for _ in range(2):  # the second download reads what the first left in the caches
+            got = ctx.hiz_download(view=2)
+            for k, (x, y) in enumerate(zip(got, ref)):
+                assert x.view("<u4").tobytes() == y.view("<u4").tobytes(), "level %d differs" % k
+
+
 def test_hiz_large_closed_form(mc, ctx):
     """8192^2 (config 5's size): level k equals the block minimum of level 0 (size-independent property)."""
     import torch

@@ -39,7 +39,7 @@ int main() {
         for (uint32_t i = 0; i < levels; i++) { tbl[i] = std::max(1u, w >> i); tbl[16 + i] = std::max(1u, h >> i); tbl[32 + i] = (uint32_t)total; total += (uint64_t)tbl[i] * tbl[16 + i]; }
         float *depth, *pyr, *pyr_ref; uint32_t *dtbl, *counter;
         CK(hipMalloc(&depth, (size_t)w * h * 4)); CK(hipMalloc(&pyr, total * 4)); CK(hipMalloc(&pyr_ref, total * 4));
-        CK(hipMalloc(&dtbl, sizeof tbl)); CK(hipMalloc(&counter, 1024)); CK(hipMemset(counter, 0, 1024));
+        CK(hipMalloc(&dtbl, sizeof tbl)); CK(hipMalloc(&counter, kHizCounterBytes)); CK(hipMemset(counter, 0, kHizCounterBytes));
         CK(hipMemcpy(dtbl, tbl, sizeof tbl, hipMemcpyHostToDevice));
         {
             std::vector<float> hd((size_t)w * h); srand(3);

@@ -6,8 +6,8 @@
 // every texel of level k depends only on its own aligned 2^k x 2^k block of level 0, so one
 // workgroup can produce levels 0..6 of a 64x64 tile from a single read of the depth image:
 // levels 1-2 in registers (4x4 texels per thread), 3-6 through LDS.  Each workgroup contributes
-// exactly one level-6 texel; the workgroup that finishes last (atomic ticket, agent-scope
-// release/acquire) reduces the remaining levels.  min() is written as (y < x ? y : x), GLSL's
+// exactly one level-6 texel; the remaining levels are reduced inside the same launch by the waves
+// that finish last (two tiers of atomic tickets, write-through stores + agent-scope acquire).  min() is written as (y < x ? y : x), GLSL's
 // definition, so the result is bit-identical to the level-by-level evaluation for every input
 // including NaN and signed zero.
 #include "mcull_internal.h"
@@ -16,7 +16,7 @@ namespace mcull {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 64;
-constexpr uint32_t kTicketGroups = 255;  // + 1 top counter = 1 KiB of ticket words
+constexpr uint32_t kMaxSinglePass = 8192;  // 128x128 tiles = 16x16 ticket groups + 1 top word (kHizCounterBytes)
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y : x; }
@@ -100,18 +100,40 @@ __device__ __forceinline__ void lds_levels(float (*s2)[17], float (*s3)[9], floa
 #undef HIZ_LDS_LEVEL
 }
 
-// Stores an N x N register patch of level K whose top-left texel is (x0, y0).
-template <int N>
-__device__ __forceinline__ void store_patch(float *__restrict__ pyr, const uint32_t *__restrict__ tbl, uint32_t K,
-                                            uint32_t levels, uint32_t x0, uint32_t y0, const float *v) {
-    if (levels <= K) return;
+// Texels handed from one workgroup to another inside a launch are stored write-through and read
+// back with agent-scope loads, which are served coherently across the XCDs' L2s.  That keeps the
+// hand-off free of cache-wide operations: an acquire fence would invalidate the reader's whole L2
+// once per ticket group, and those invalidations pile up at the end of a launch that fits the
+// machine in one round (measured +8 us at 3840x2160).
+__device__ __forceinline__ float coherent_load(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One level inside a wave.  Lanes [0, N*N) hold, row-major, the N x N block of level K-1 whose
+// top-left texel is (2*ox, 2*oy); returns in lanes [0, N*N/4) the N/2 x N/2 block of level K at
+// (ox, oy) and stores its texels that lie inside the level.  Child indices clamp to the last valid
+// texel of the source level inside the block (matters only when that extent has collapsed to 1).
+// Every lane of the wave must call this (the shuffles are wave-wide).  WT: write-through store.
+template <int N, bool WT>
+__device__ __forceinline__ float wave_level(float v, uint32_t K, uint32_t levels, uint32_t ox, uint32_t oy,
+                                            float *__restrict__ pyr, const uint32_t *__restrict__ tbl, uint32_t lane) {
+    if (levels <= K) return v;  // uniform
+    constexpr uint32_t H = N / 2;
+    const uint32_t x = lane % H, y = (lane / H) % H;
+    const uint32_t sw = tbl[K - 1], sh = tbl[16 + K - 1];
+    const uint32_t mx = sw > 2u * ox ? min(sw - 1u - 2u * ox, (uint32_t)N - 1u) : 0u;
+    const uint32_t my = sh > 2u * oy ? min(sh - 1u - 2u * oy, (uint32_t)N - 1u) : 0u;
+    const uint32_t cx0 = min(2u * x, mx), cx1 = min(2u * x + 1u, mx), cy0 = min(2u * y, my), cy1 = min(2u * y + 1u, my);
+    const float d0 = __shfl(v, (int)(cy0 * N + cx0)), d1 = __shfl(v, (int)(cy0 * N + cx1));
+    const float d2 = __shfl(v, (int)(cy1 * N + cx0)), d3 = __shfl(v, (int)(cy1 * N + cx1));
+    const float r = min4(d0, d1, d2, d3);
     const uint32_t lw = tbl[K], lh = tbl[16 + K];
-    float *dst = pyr + tbl[32 + K];
-#pragma unroll
-    for (int j = 0; j < N; j++)
-#pragma unroll
-        for (int i = 0; i < N; i++)
-            if (x0 + i < lw && y0 + j < lh) dst[(size_t)(y0 + j) * lw + x0 + i] = v[j * N + i];
+    if (lane < H * H && ox + x < lw && oy + y < lh) {
+        float *dst = pyr + tbl[32 + K] + (size_t)(oy + y) * lw + ox + x;
+        if (WT) __hip_atomic_store(dst, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = r;
+    }
+    return r;
 }
 
 // Tiled kernel.  grid = (tiles_x, tiles_y), 256 threads, thread (tx,ty) = (t&15, t>>4) owns the
@@ -124,7 +146,6 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     __shared__ float s3[8][9];
     __shared__ float s4[4][5];
     __shared__ float s5[2][3];
-    __shared__ uint32_t s_last;
     const uint32_t t = threadIdx.x, tx = t & 15u, ty = t >> 4;
     const uint32_t x0 = blockIdx.x * kTile + 4 * tx, y0 = blockIdx.y * kTile + 4 * ty;
 
@@ -186,79 +207,61 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
 
     if (!SINGLE_PASS || levels <= 7) return;
 
-    // ---- levels 7..: done by the workgroup that arrives last.  Each workgroup produced exactly one
-    // level-6 texel, written by thread 0 with a write-through (agent-scope) store; thread 0 drains
-    // that store and then takes a ticket.  No L2 write-back is needed on the producer side.  The
-    // last arriver acquires at agent scope (one lane), the barrier releases the other waves.
-    // Tickets are two-level (up to kTicketGroups group counters + one top counter): a single word
-    // sustains only ~90 returning atomics per microsecond, which 16 384 workgroups would queue on.
+    // ---- levels 7..: handed to whichever workgroup finishes last, by wave 0 alone (waves 1-3 are done
+    // and leave; nothing below uses a workgroup barrier or LDS).  Each workgroup produced exactly one
+    // level-6 texel, written by thread 0 with a write-through (agent-scope) store; wave 0 drains that
+    // store and takes a ticket in the counter of its 8x8 block of tiles.  The last arriver of a block
+    // owns that block's 8x8 level-6 texels = one texel per lane, reduces levels 7-9 with lane
+    // shuffles, and takes a ticket in the top counter; the last arriver there reduces the (at most
+    // 16x16) level-9 texels to the apex.  A consumer's loads are issued only after its ticket has
+    // returned, and every producer's texel had reached memory before its ticket was taken, so no
+    // L2 write-back or invalidate is needed on either side, and no
+    // word receives more than 256 tickets (a single word sustains only ~90 returning atomics per
+    // microsecond, which 16 384 workgroups would queue on).
+    if (t >= 64u) return;
+    const uint32_t gx = blockIdx.x >> 3, gy = blockIdx.y >> 3;
+    const uint32_t groups_x = (gridDim.x + 7u) >> 3, groups_y = (gridDim.y + 7u) >> 3;
+    uint32_t last = 0u;
     if (t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t n_wg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const uint32_t n_grp = n_wg < kTicketGroups ? n_wg : kTicketGroups;
-        const uint32_t grp = lin % n_grp, members = (n_wg - grp + n_grp - 1u) / n_grp;
-        uint32_t last = 0u;
-        if (__hip_atomic_fetch_add(counter + 1u + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)
-            last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_grp - 1u;
-        s_last = last;
+        const uint32_t members = min(8u, gridDim.x - 8u * gx) * min(8u, gridDim.y - 8u * gy);
+        last = __hip_atomic_fetch_add(counter + 1u + gy * groups_x + gx, 1u, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT) == members - 1u;
     }
-    __syncthreads();
-    if (s_last == 0u) return;
+    if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    {
+        const uint32_t w6 = tbl[6], h6 = tbl[16 + 6];
+        const uint32_t x = min(8u * gx + (t & 7u), w6 - 1u), y = min(8u * gy + (t >> 3), h6 - 1u);
+        float v = coherent_load(pyr + tbl[32 + 6] + (size_t)y * w6 + x);
+        v = wave_level<8, false>(v, 7u, levels, 4u * gx, 4u * gy, pyr, tbl, t);
+        v = wave_level<4, false>(v, 8u, levels, 2u * gx, 2u * gy, pyr, tbl, t);
+        v = wave_level<2, true>(v, 9u, levels, gx, gy, pyr, tbl, t);
+    }
+    last = 0u;
     if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups_x * groups_y - 1u;
     }
-    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
     // every ticket of this launch has been taken: leave the words zero for the next launch on the
     // stream (they are zeroed once at allocation; no per-call memset is needed)
-    if (t <= kTicketGroups) counter[t] = 0u;
-    const uint32_t w6 = tbl[6], h6 = tbl[16 + 6];
-    if (w6 > 128u || h6 > 128u) {  // images beyond 8192 texels a side: level by level from memory
-        reduce_levels_from_global(pyr, tbl, 7, levels);
-        return;
-    }
-    // Thread (tx,ty) owns the 8x8 patch of level 6 at (8*tx, 8*ty): levels 7-9 in registers, then the
-    // 16x16 level-9 values go through the same LDS ladder for levels 10-13.  A child index beyond the
-    // source extent can only occur when that extent is 1; it then clamps to texel 0.
+    for (uint32_t i = t; i <= groups_x * groups_y; i += 64u) counter[i] = 0u;
+    if (levels <= 10) return;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     {
-        const float *l6 = pyr + tbl[32 + 6];
-        float q[8][8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t y = min(8 * ty + r, h6 - 1);
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const uint32_t x = min(8 * tx + c, w6 - 1);
-                q[r][c] = l6[(size_t)y * w6 + x];
-            }
-        }
-        const bool cx6 = (w6 == 1u), cy6 = (h6 == 1u);
-        float q7[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int x1 = cx6 ? 2 * i : 2 * i + 1, y1 = cy6 ? 2 * j : 2 * j + 1;
-                q7[j][i] = min4(q[2 * j][2 * i], q[2 * j][x1], q[y1][2 * i], q[y1][x1]);
-            }
-        store_patch<4>(pyr, tbl, 7, levels, 4 * tx, 4 * ty, &q7[0][0]);
-        const bool cx7 = (tbl[7] == 1u), cy7 = (tbl[16 + 7] == 1u);
-        float q8[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int x1 = cx7 ? 2 * i : 2 * i + 1, y1 = cy7 ? 2 * j : 2 * j + 1;
-                q8[j][i] = min4(q7[2 * j][2 * i], q7[2 * j][x1], q7[y1][2 * i], q7[y1][x1]);
-            }
-        store_patch<2>(pyr, tbl, 8, levels, 2 * tx, 2 * ty, &q8[0][0]);
-        const bool cx8 = levels > 8 && tbl[8] == 1u, cy8 = levels > 8 && tbl[16 + 8] == 1u;
-        const float q9 = min4(q8[0][0], q8[0][cx8 ? 0 : 1], q8[cy8 ? 0 : 1][0], q8[cy8 ? 0 : 1][cx8 ? 0 : 1]);
-        store_patch<1>(pyr, tbl, 9, levels, tx, ty, &q9);
-        __syncthreads();  // s2 is free again: every wave has finished the tile's LDS ladder
-        s2[ty][tx] = q9;
-        __syncthreads();
-        lds_levels<false>(s2, s3, s4, s5, pyr, tbl, levels, 9u, 0u, 0u, t);
+        // lane (x,y) of an 8x8 arrangement owns the 2x2 patch of level 9 at (2x,2y) -> one texel of level 10
+        const uint32_t w9 = tbl[9], h9 = tbl[16 + 9];
+        const float *l9 = pyr + tbl[32 + 9];
+        const uint32_t x0 = min(2u * (t & 7u), w9 - 1u), x1 = min(2u * (t & 7u) + 1u, w9 - 1u);
+        const uint32_t y0 = min(2u * (t >> 3), h9 - 1u), y1 = min(2u * (t >> 3) + 1u, h9 - 1u);
+        float v = min4(coherent_load(l9 + (size_t)y0 * w9 + x0), coherent_load(l9 + (size_t)y0 * w9 + x1),
+                       coherent_load(l9 + (size_t)y1 * w9 + x0), coherent_load(l9 + (size_t)y1 * w9 + x1));
+        const uint32_t w10 = tbl[10], h10 = tbl[16 + 10];
+        if ((t & 7u) < w10 && (t >> 3) < h10) pyr[tbl[32 + 10] + (size_t)(t >> 3) * w10 + (t & 7u)] = v;
+        v = wave_level<8, false>(v, 11u, levels, 0u, 0u, pyr, tbl, t);
+        v = wave_level<4, false>(v, 12u, levels, 0u, 0u, pyr, tbl, t);
+        v = wave_level<2, false>(v, 13u, levels, 0u, 0u, pyr, tbl, t);
     }
 }
 
@@ -272,7 +275,7 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
     const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
                      (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u;
-    if (single_pass && levels > 7) {
+    if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
         if (vec)
             hipLaunchKernelGGL((hiz_tile_kernel<true, true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
                                level_table, levels, counter);

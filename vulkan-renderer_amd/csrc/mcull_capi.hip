@@ -443,8 +443,8 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
     if ((rc = ensure(c, s.pyramid, total * 4))) return rc;
     if ((rc = ensure(c, s.table, 48 * 4))) return rc;
     if (!c->hiz_counter.p) {  // ticket words: zero once; the kernel's last workgroup re-zeroes them
-        if ((rc = ensure(c, c->hiz_counter, 1024))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->hiz_counter.p, 0, 1024, c->stream));
+        if ((rc = ensure(c, c->hiz_counter, mcull::kHizCounterBytes))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->hiz_counter.p, 0, mcull::kHizCounterBytes, c->stream));
     }
     if (!s.built || s.w != width || s.h != height) {
         uint32_t tbl[48];
