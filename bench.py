@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the GPU-driven culling path: meshlet-instances culled + compacted per second.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config5|hiz|bounds]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (per GPU, weak scaling): the synthetic 100 M meshlet-instance scene — 781 250 instances x
-128 unique meshlets each (3.2 GB of SoA bounds resident in HBM), frustum + backface-cone tests,
-ordered compaction into one visible list + one VkDrawMeshTasksIndirectCommandNV per instance.  One
-step = one pass of the hot path (cull mask -> compact -> emit commands) over that scene; with N > 1
-every rank culls its own shard and the per-rank visible counts and per-instance commands are
+Default workload (per GPU, weak scaling): the synthetic 100 M meshlet-instance scene — 781 250
+instances x 128 unique meshlets each (3.2 GB of SoA bounds resident in HBM), frustum + backface-cone
+tests, ordered compaction into one visible list + one VkDrawMeshTasksIndirectCommandNV per instance.
+One step = one pass of the hot path (cull mask -> compact -> emit commands) over that scene; with
+N > 1 every rank culls its own shard and the per-rank visible counts and per-instance commands are
 all-gathered over RCCL into one global draw list description (firstTask rebased by the gathered
 counts on the device, no host round trip).
 
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the kernels of each
-step on the stream they run on, `cpu_baseline` times the CPU oracle (a port of the reference shader,
-the reference has no CPU culling path) on this host's cores.
+Other workloads (each prints its own single JSON line):
+  config3  1 M instances of one 13 916-meshlet mesh (13.9 G meshlet-instances) with Hi-Z against a
+           3840x2160 pyramid; shared bounds, so the bound is the per-pair arithmetic and the list
+  config5  the default scene culled against 8 views, each with its own 8192^2 pyramid rebuilt in the
+           step (8 x (pyramid build + cull))
+  hiz      the 8192^2 pyramid build alone (9.33 algorithmic bytes per pixel)
+  bounds   cone/sphere computation for 64 copies of the kitten fixture's meshlets
+
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the kernels of the
+timed region on the stream they run on, `cpu_baseline` times the CPU oracle (a port of the
+reference shader / CPU code; the reference has no CPU culling path) on this host's cores.
 """
 import argparse
 import ctypes
@@ -51,6 +59,10 @@ def make_scene(device, n_inst, per, seed):
         b = min(n, a + chunk)
         sphere[a:b, :3] = torch.rand((b - a, 3), device=device, generator=gen)
         sphere[a:b, 3] = 0.01 + 0.04 * torch.rand(b - a, device=device, generator=gen)
+    return cone, sphere, make_transforms(device, n_inst, 50.0, gen)
+
+
+def make_transforms(device, n_inst, extent, gen):
     q = torch.randn((n_inst, 4), device=device, generator=gen)
     q = q / q.norm(dim=1, keepdim=True)
     w, x, y, z = q.unbind(1)
@@ -58,63 +70,176 @@ def make_scene(device, n_inst, per, seed):
     m[:, 0, 0] = 1 - 2 * (y * y + z * z); m[:, 1, 0] = 2 * (x * y - z * w); m[:, 2, 0] = 2 * (x * z + y * w)
     m[:, 0, 1] = 2 * (x * y + z * w); m[:, 1, 1] = 1 - 2 * (x * x + z * z); m[:, 2, 1] = 2 * (y * z - x * w)
     m[:, 0, 2] = 2 * (x * z - y * w); m[:, 1, 2] = 2 * (y * z + x * w); m[:, 2, 2] = 1 - 2 * (x * x + y * y)
-    m[:, 3, :3] = (torch.rand((n_inst, 3), device=device, generator=gen) * 2 - 1) * 50.0
+    m[:, 3, :3] = (torch.rand((n_inst, 3), device=device, generator=gen) * 2 - 1) * extent
     m[:, 3, 3] = 1.0
-    return cone, sphere, m.reshape(n_inst, 16).contiguous()
+    return m.reshape(n_inst, 16).contiguous()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--instances", type=int, default=781250)
-    ap.add_argument("--meshlets-per-instance", type=int, default=128)
-    ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
-    ap.add_argument("--hiz", action="store_true", help="also run the Hi-Z test against a 4K pyramid")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
-    args = ap.parse_args()
+class Env:
+    """Process-wide state shared by the workloads: ranks, the library, the timing primitives."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    multi = world > 1 or args.force_dist
-    if multi:
-        import torch.distributed as dist
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.multi = self.world > 1 or args.force_dist
+        self.dist = None
+        if self.multi:
+            import torch.distributed as dist
 
-        if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+            if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl", device_id=self.device)
+            self.dist = dist
+        self.mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
+        self.host = importlib.import_module("vulkan-renderer_amd.host")
+        self.mdist = importlib.import_module("vulkan-renderer_amd.dist")
+        self.ctx = self.mc.Context(self.local_rank)
+        # HIP events on the stream the kernels are launched on (the context's stream = the null
+        # stream), bracketing exactly the timed region
+        self.hip = ctypes.CDLL("libamdhip64.so.7")
+        self.ev0, self.ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(self.ev0)) == 0 and self.hip.hipEventCreate(ctypes.byref(self.ev1)) == 0
 
-    mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
-    host = importlib.import_module("vulkan-renderer_amd.host")
-    mdist = importlib.import_module("vulkan-renderer_amd.dist")
-    ctx = mc.Context(local_rank)
+    def fence(self):
+        if self.multi:
+            self.dist.barrier()
+        torch.cuda.synchronize()
 
-    n_inst, per = args.instances, args.meshlets_per_instance
+    def timed(self, step, steps=None, warmup=None):
+        """W untimed steps, then K steps between barrier+synchronize fences.  Returns (wall seconds,
+        max over ranks; device milliseconds between HIP events on the kernels' stream)."""
+        steps = self.args.steps if steps is None else steps
+        warmup = self.args.warmup if warmup is None else warmup
+        for k in range(warmup):
+            step(k)
+        self.fence()
+        t0 = time.perf_counter()
+        assert self.hip.hipEventRecord(self.ev0, None) == 0
+        for k in range(steps):
+            step(k)
+        assert self.hip.hipEventRecord(self.ev1, None) == 0
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        dev_ms = ctypes.c_float()
+        assert self.hip.hipEventElapsedTime(ctypes.byref(dev_ms), self.ev0, self.ev1) == 0
+        if self.multi:
+            te = torch.tensor([elapsed], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(te, op=self.dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        return elapsed, dev_ms.value
+
+    def line(self, out):
+        if self.rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def close(self):
+        if self.multi:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        self.ctx.close()
+
+
+def base_line(env, metric, unit, value, elapsed, steps, workload, extra_config=None):
+    a = env.args
+    cfg = {"workload": workload}
+    cfg.update(extra_config or {})
+    return {
+        "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": env.world, "steps": steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "config": cfg,
+    }
+
+
+def roofline(algo_bytes, kernel_ms, kernel_name, traffic=None, traffic_src=None, **extra):
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(algo_bytes)}
+    r.update(extra)
+    return r
+
+
+def host_threads():
+    import oracle as O
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    return max(1, min(threads, O.max_threads()))
+
+
+def time_cpu(fn, budget_s, max_reps=400):
+    reps, used = 0, 0.0
+    while used < budget_s and reps < max_reps:
+        t0 = time.perf_counter()
+        fn()
+        used += time.perf_counter() - t0
+        reps += 1
+    return reps, used
+
+
+# ------------------------------------------------------------------------------------------------
+# cull workloads (config 4 = default, config 3, config 5)
+
+def run_cull(env, workload):
+    args, mc, ctx, device = env.args, env.mc, env.ctx, env.device
+    rank, world, multi, dist = env.rank, env.world, env.multi, env.dist
+    n_views = 1
+    if workload == "config3":
+        n_inst, per = (args.instances or 1_000_000), (args.meshlets_per_instance or 13916)
+        gen = torch.Generator(device=device).manual_seed(77 + rank)
+        c_np, s_np = env.host.synthetic_bounds(per, seed=5)  # one shared mesh
+        cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
+        xf = make_transforms(device, n_inst, 70.0, gen)
+        ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=per, mem=mc.MEM_DEVICE, adopt=True)
+        ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
+        off = cnt = None
+        g = env.host.create_globals(eye=(90.0, 85.0, 60.0), width=3840, height=2160, flip_y=False, meshlet_count=per)
+        use_hiz, hiz_size = True, (3840, 2160)
+        unique = per
+    else:
+        n_inst, per = (args.instances or 781250), (args.meshlets_per_instance or 128)
+        cone, sphere, xf = make_scene(device, n_inst, per, seed=42 + rank)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE, adopt=True)
+        ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
+        ctx.set_instance_ranges(off, cnt)
+        g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
+        use_hiz, hiz_size = args.hiz, (3840, 2160)
+        unique = n_inst * per
+        if workload == "config5":
+            n_views, use_hiz, hiz_size = 8, True, (8192, 8192)
     n_pairs = n_inst * per
-    cone, sphere, xf = make_scene(device, n_inst, per, seed=42 + rank)
-    off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
-    cnt = np.full(n_inst, per, dtype="<u4")
-    ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_pairs, mem=mc.MEM_DEVICE, adopt=True)
-    ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
-    ctx.set_instance_ranges(off, cnt)
-    g = host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
     tests = mc.TEST_FRUSTUM | mc.TEST_CONE
-    if args.hiz:
-        depth = torch.from_numpy(host.synthetic_depth(3840, 2160, 64, 1234)).to(device)
-        ctx.hiz_build(depth.data_ptr(), view=0, width=3840, height=2160, mem=mc.MEM_DEVICE)
+    views = [g]
+    depth = None
+    if use_hiz:
         tests |= mc.TEST_HIZ
+        w, h = hiz_size
+        if workload == "config5":
+            gen = torch.Generator(device=device).manual_seed(3)
+            coarse = torch.rand((64, 64), device=device, generator=gen)
+            d = torch.where(coarse > 0.6, coarse * 0.05, torch.zeros_like(coarse))
+            depth = d.repeat_interleave(h // 64, 0).repeat_interleave(w // 64, 1).contiguous()
+            views = []
+            for v in range(8):
+                ang = 2 * np.pi * v / 8
+                views.append(env.host.create_globals(eye=(120 * np.cos(ang), 120 * np.sin(ang), 40.0 + 10 * v),
+                                                     fov_deg=30.0 + 5 * v, width=w, height=h, flip_y=bool(v & 1)))
+        else:
+            depth = torch.from_numpy(env.host.synthetic_depth(w, h, 64, 1234)).to(device)
+        for v in range(n_views):
+            ctx.hiz_build(depth.data_ptr(), view=v, width=w, height=h, mem=mc.MEM_DEVICE)
 
     # caller-owned outputs (torch owns what the collectives touch); commands and counts are double
     # buffered so that the gather of step k overlaps the cull of step k+1
-    lst = torch.empty((n_pairs, 2), device=device, dtype=torch.int32)
+    cap = n_pairs if workload != "config3" else (1 << 30)
+    lst = torch.empty((cap, 2), device=device, dtype=torch.int32)
     cmds = [torch.zeros((n_inst, 2), device=device, dtype=torch.int32) for _ in range(2)]
     total = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(2)]
     kernel_ms = []
@@ -125,12 +250,20 @@ def main():
         ev_comm = [torch.cuda.Event() for _ in range(2)]
         main = torch.cuda.current_stream(device)
 
-    def step(k, record=False):
+    def step(k, record=False, gather_lists=False):
         b = k & 1
         if multi:
             main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
-        ctx.cull(g, tests=tests, compaction=args.compaction, list_ptr=lst.data_ptr(), list_capacity=n_pairs,
-                 commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+        ms = 0.0
+        for v in range(n_views):
+            if workload == "config5":  # the pyramid of every view is rebuilt from its depth each step
+                ctx.hiz_build(depth.data_ptr(), view=v, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
+                if record:
+                    ms += ctx.last_kernel_ms()
+            ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
+                     list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+            if record:
+                ms += ctx.last_kernel_ms()
         if multi:
             # per-rank counts -> every rank's list offset -> rebased per-instance commands, gathered
             # into one global draw-list description; runs on a side stream beside the next cull
@@ -141,95 +274,77 @@ def main():
                 def rebase(totals_all, rk, cb=cmds[b]):
                     cb[:, 1] += totals_all[:rk].sum().to(torch.int32)
 
-                gathered[b] = mdist.gather_draw_list(total[b], cmds[b], rebase)
+                gathered[b] = env.mdist.gather_draw_list(total[b], cmds[b], rebase)
+                if gather_lists:
+                    env.mdist.gather_visible_lists(lst, gathered[b][0])
                 ev_comm[b].record(comm)
         if record:
-            kernel_ms.append(ctx.last_kernel_ms())
+            kernel_ms.append(ms)
 
-    def fence():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # HIP events on the stream the kernels are launched on (the context's stream = the null stream),
-    # bracketing exactly the timed region
-    hip = ctypes.CDLL("libamdhip64.so.7")
-    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
-    assert hip.hipEventCreate(ctypes.byref(ev0)) == 0 and hip.hipEventCreate(ctypes.byref(ev1)) == 0
-
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    t0 = time.perf_counter()
-    assert hip.hipEventRecord(ev0, None) == 0
-    for k in range(args.steps):
-        step(k)
-    assert hip.hipEventRecord(ev1, None) == 0
-    fence()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ctypes.c_float()
-    assert hip.hipEventElapsedTime(ctypes.byref(dev_ms), ev0, ev1) == 0
-    region_ms_per_step = dev_ms.value / args.steps
-    if multi:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed, dev_ms = env.timed(step)
+    region_ms_per_step = dev_ms / args.steps
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
     for k in range(min(args.steps, 10)):
         step(k, record=True)
-    fence()
+    ctx.enable_timing(False)
+    env.fence()
     visible = int(total[0].item())
+    with_lists = None
     if multi:  # the gathered description must be consistent on every rank
         totals_all, cmds_all = gathered[0]
         assert totals_all.numel() == world and cmds_all.shape[0] == world * n_inst
         mine = cmds_all[rank * n_inst:(rank + 1) * n_inst].to(torch.int64)
         assert int(mine[:, 0].sum()) == int(totals_all[rank]) and int(mine[0, 1]) == int(totals_all[:rank].sum())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_pairs * world / (elapsed / args.steps) / 1e9
+        if args.gather_lists:
+            # the same step including the optional all-gather of the visible lists themselves
+            # (padded to the largest shard; link-bound over xGMI), timed separately
+            el2, _ = env.timed(lambda k: step(k, gather_lists=True), steps=min(args.steps, 5), warmup=1)
+            n2 = min(args.steps, 5)
+            with_lists = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(n_pairs * n_views * world / (el2 / n2) / 1e9, 3),
+                          "list_bytes_per_rank": int(totals_all.max()) * 8 * world}
+    value = n_pairs * n_views * world / (elapsed / args.steps) / 1e9
 
     if rank == 0:
         k_ms = region_ms_per_step if world == 1 else float(np.mean(kernel_ms))
-        n_hz = 0
-        algo = 32.0 * n_pairs + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible + 4.0 * n_hz
-        achieved = algo / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args, n_inst, per)
-        out = {
-            "metric": "meshlet-instances culled+compacted/sec", "value": round(value, 3), "unit": "G/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "config 4: synthetic scene, %d instances x %d unique meshlets = %d meshlet-instances per GPU, "
-                            "frustum+cone%s, %s compaction" % (n_inst, per, n_pairs, "+hiz(4K)" if args.hiz else "",
-                                                               ["ordered", "wave-atomic", "block-atomic"][args.compaction]),
-                "meshlet_instances_per_gpu": n_pairs, "visible_fraction": round(visible / n_pairs, 4),
-                "parallelism": ("instances sharded x%d, RCCL all-gather of counts + rebased commands overlapped with the next cull" % world)
-                if multi else "single GPU",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)",
-                "kernel_ms": round(k_ms, 4), "kernel_ms_single_call": round(float(np.mean(kernel_ms)), 4),
-                "algorithmic_bytes": int(algo),
-                "bytes_per_pair": round(algo / n_pairs, 2),
-            },
-        }
+        algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
+        kernels = "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)"
+        extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / n_pairs, 4),
+                     "parallelism": ("instances sharded x%d, RCCL all-gather of counts + rebased commands overlapped with the next cull" % world)
+                     if multi else "single GPU"}
+        if workload == "config5":
+            w, h = hiz_size
+            algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
+            kernels = "8 x (hiz_tile_kernel + cull_mask_kernel + compact_kernel + emit_commands_kernel)"
+            name = ("config 5: %d instances x %d unique meshlets against 8 views, one 8192^2 Hi-Z pyramid per view rebuilt "
+                    "every step, frustum+cone+hiz, ordered compaction (visible fraction is the last view's)" % (n_inst, per))
+        elif workload == "config3":
+            name = ("config 3: %d instances of one %d-meshlet mesh = %d meshlet-instances per GPU, frustum+cone+hiz against a "
+                    "3840x2160 pyramid (unflipped projection), ordered compaction; bounds are shared, so the HBM figure "
+                    "counts little more than the visible list and excludes the Hi-Z texel reads" % (n_inst, per, n_pairs))
+        else:
+            name = ("config 4: synthetic scene, %d instances x %d unique meshlets = %d meshlet-instances per GPU, frustum+cone%s, "
+                    "%s compaction" % (n_inst, per, n_pairs, "+hiz(4K)" if args.hiz else "",
+                                       ["ordered", "wave-atomic", "block-atomic"][args.compaction]))
+        out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", value, elapsed, args.steps, name, extra_cfg)
+        traffic, traffic_src = pmc_traffic(args, workload, n_inst, per)
+        out["roofline"] = roofline(algo, k_ms, kernels, traffic, traffic_src,
+                                   kernel_ms_single_call=round(float(np.mean(kernel_ms)), 4),
+                                   bytes_per_pair=round(algo / (n_pairs * n_views), 2))
+        if with_lists:
+            out["with_list_gather"] = with_lists
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cone, sphere, xf, off, cnt, g, tests, n_inst, per)
-        print(json.dumps(out), flush=True)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+            out["cpu_baseline"] = cpu_baseline_cull(cone, sphere, xf, off, cnt, views[-1], tests, n_inst, per,
+                                                    None if depth is None else depth, hiz_size, workload)
+        env.line(out)
 
 
-def pmc_traffic(args, n_inst, per):
+def pmc_traffic(args, workload, n_inst, per):
     """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE
     doubled as the gfx950 correction prescribes, WRITE_SIZE as is; separate passes), or None when the
     workload differs from the profiled one.  Counters cannot be collected from inside this process."""
     path = os.path.join(ROOT, "profiles", "r01_bench_config4_summary.json")
-    if (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False) or not os.path.exists(path):
+    if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False) or not os.path.exists(path):
         return None, None
     with open(path) as f:
         summ = json.load(f)
@@ -240,29 +355,153 @@ def pmc_traffic(args, n_inst, per):
     return (total or None), "profiles/r01_bench_config4_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
 
 
-def cpu_baseline(cone, sphere, xf, off, cnt, g, tests, n_inst, per):
-    """The CPU oracle (a port of shaders/shader.task, test infrastructure) timed on this host."""
+def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):
+    """The CPU oracle (a port of shaders/shader.task, test infrastructure) timed on this host: all
+    host threads (OpenMP over instances) and one thread, on a bounded sample of the same scene."""
     import oracle as O
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    threads = max(1, min(threads, O.max_threads()))
-    sample = min(n_inst, 262144)  # 33.5 M pairs, ~1 GB of bounds on the host
-    c = cone[: sample * per].cpu().numpy()
-    s = sphere[: sample * per].cpu().numpy()
+    threads = host_threads()
+    shared = off is None
+    sample = min(n_inst, 262144 if not shared else 2048)  # ~30 M pairs either way
+    rows = sample * per if not shared else per
+    c = cone[:rows].cpu().numpy()
+    s = sphere[:rows].cpu().numpy()
     t = np.zeros(sample, dtype=O.TRANSFORM)
     t["model"] = xf[:sample].cpu().numpy()
-    view = O.View(g)
-    rng = (off[:sample], cnt[:sample])
-    O.cull_scene(view, t[:1024], cone_axis_w=c, centre_radius=s, ranges=(off[:1024], cnt[:1024]), tests=tests, threads=threads)
-    reps, t_used = 0, 0.0
-    while t_used < 10.0 and reps < 400:
-        t0 = time.perf_counter()
-        r = O.cull_scene(view, t, cone_axis_w=c, centre_radius=s, ranges=rng, tests=tests, threads=threads)
-        t_used += time.perf_counter() - t0
-        reps += 1
-    return {"value": round(sample * per * reps / t_used / 1e9, 4), "unit": "G/s", "cores": threads, "kind": "port",
-            "sample": "first %d instances (%d meshlet-instances) of the same scene, %d passes, OpenMP over instances"
-                      % (sample, sample * per, reps)}
+    if tests & 4:
+        w, h = hiz_size
+        view = O.View(g, O.hiz_build(depth.cpu().numpy(), threads=threads), w, h)
+    else:
+        view = O.View(g)
+    rng = None if shared else (off[:sample], cnt[:sample])
+
+    def run(n, th):
+        return O.cull_scene(view, t[:n], cone_axis_w=c, centre_radius=s, ranges=None if shared else (off[:n], cnt[:n]),
+                            tests=tests, threads=th)
+
+    run(min(sample, 1024), threads)
+    reps, used = time_cpu(lambda: run(sample, threads), 10.0)
+    one = max(1, sample // 8)
+    reps1, used1 = time_cpu(lambda: run(one, 1), 4.0)
+    return {"value": round(sample * per * reps / used / 1e9, 4), "unit": "G/s", "cores": threads, "kind": "port",
+            "value_1_thread": round(one * per * reps1 / used1 / 1e9, 4),
+            "sample": "first %d instances (%d meshlet-instances) of the same scene, %d passes, OpenMP over instances; "
+                      "1 thread: first %d instances, %d passes" % (sample, sample * per, reps, one, reps1)}
+
+
+# ------------------------------------------------------------------------------------------------
+# Hi-Z pyramid build alone
+
+def run_hiz(env):
+    args, mc, ctx, device = env.args, env.mc, env.ctx, env.device
+    w, h = args.hiz_size
+    gen = torch.Generator(device=device).manual_seed(11 + env.rank)
+    depth = torch.rand((h, w), device=device, dtype=torch.float32, generator=gen)
+
+    def step(k):
+        ctx.hiz_build(depth.data_ptr(), view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+
+    elapsed, dev_ms = env.timed(step)
+    levels, _, _, _, total = mc.hiz_layout(w, h)
+    algo = 4.0 * w * h + 4.0 * total
+    value = w * h * env.world / (elapsed / args.steps) / 1e9
+    if env.rank == 0:
+        out = base_line(env, "Hi-Z pyramid pixels reduced/sec", "Gpixel/s", value, elapsed, args.steps,
+                        "Hi-Z min pyramid of a %dx%d depth image, %d levels, one launch%s"
+                        % (w, h, levels, " (replicas: every GPU builds its own)" if env.world > 1 else ""))
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_tile_kernel", bytes_per_pixel=round(algo / (w * h), 3))
+        if not args.no_cpu_baseline and env.world == 1:
+            import oracle as O
+
+            threads = host_threads()
+            d = depth.cpu().numpy()
+            O.hiz_build(d, threads=threads)
+            reps, used = time_cpu(lambda: O.hiz_build(d, threads=threads), 8.0)
+            reps1, used1 = time_cpu(lambda: O.hiz_build(d, threads=1), 6.0)
+            out["cpu_baseline"] = {"value": round(w * h * reps / used / 1e9, 4), "unit": "Gpixel/s", "cores": threads, "kind": "port",
+                                   "value_1_thread": round(w * h * reps1 / used1 / 1e9, 4),
+                                   "sample": "the same %dx%d image, level by level as shader.comp, %d passes on %d threads, %d on one"
+                                             % (w, h, reps, threads, reps1)}
+        env.line(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# meshlet bounds (cone + sphere) — load-time work of Engine::buildMeshletCon
+
+def run_bounds(env):
+    args, mc, ctx = env.args, env.mc, env.ctx
+    copies = 64
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kitten_scene.npz"))
+    ml, md, vt = z["meshlets"].view(mc.MESHLET), z["meshlet_data"], z["vertices"].view(mc.VERTEX)
+    mls = []
+    for c in range(copies):
+        m2 = ml.copy()
+        m2["dataOffset"] += c * len(md)
+        mls.append(m2)
+    mls = np.concatenate(mls)
+    mds = np.tile(md, copies)
+    ctx.upload_meshlets(mls)
+    ctx.upload_geometry(vt, mds)
+
+    def step(k):
+        ctx.compute_bounds()
+
+    elapsed, dev_ms = env.timed(step)
+    v = mls["vertexCount"].astype(np.int64)
+    t = mls["triangleCount"].astype(np.int64)
+    algo = float((4 * v + 4 * ((3 * t + 3) // 4) + 12 * v + 48 + 36).sum())
+    value = len(mls) * env.world / (elapsed / args.steps) / 1e6
+    if env.rank == 0:
+        out = base_line(env, "meshlet bounds (cone+sphere) computed/sec", "M/s", value, elapsed, args.steps,
+                        "buildMeshletCon over %d copies of the kitten fixture's %d meshlets (%d meshlets, cache-resident vertices)"
+                        % (copies, len(ml), len(mls)))
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "split_meshlets_kernel + bounds_kernel",
+                                   bytes_per_meshlet=round(algo / len(mls), 1))
+        if not args.no_cpu_baseline and env.world == 1:
+            import oracle as O
+
+            reps, used = time_cpu(lambda: O.build_meshlet_cones(vt, md, ml), 5.0)
+            pos = np.ascontiguousarray(vt["pos"][:, :3])
+            tris = []  # the fixture's triangles, recovered from the packed meshlet data
+            for m in ml:
+                o, nv, nt = int(m["dataOffset"]), int(m["vertexCount"]), int(m["triangleCount"])
+                local = md[o + nv: o + nv + (3 * nt + 3) // 4].view("u1")[: 3 * nt]
+                tris.append(md[o: o + nv][local])
+            corners = np.full((sum(len(x) for x in tris), 3), -1, dtype="<i4")
+            corners[:, 0] = np.concatenate(tris)
+            t0 = time.perf_counter()
+            O.build_mesh(pos, corners)
+            whole = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(len(ml) * reps / used / 1e6, 4), "unit": "M/s", "cores": 1, "kind": "port",
+                                   "sample": "buildMeshletCon over the fixture's %d meshlets, %d passes, one thread as in the reference; "
+                                             "the whole load-time pipeline on the fixture (dedup, Forsyth reorder, meshlets, bounds) "
+                                             "takes %.3f s on one thread" % (len(ml), reps, whole)}
+        env.line(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "hiz", "bounds"])
+    ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
+    ap.add_argument("--meshlets-per-instance", type=int, default=0)
+    ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
+    ap.add_argument("--hiz", action="store_true", help="config4: also run the Hi-Z test against a 4K pyramid")
+    ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
+    ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
+    args = ap.parse_args()
+    env = Env(args)
+    if args.workload == "hiz":
+        run_hiz(env)
+    elif args.workload == "bounds":
+        run_bounds(env)
+    else:
+        run_cull(env, args.workload)
+    env.close()
 
 
 if __name__ == "__main__":

@@ -178,6 +178,15 @@ def build_meshlet_cone(vertices, meshlet_data, meshlet):
     return ml[0]
 
 
+def build_meshlet_cones(vertices, meshlet_data, meshlets):
+    """buildMeshletCon over an array of MESHLET records (returns a completed copy)."""
+    v = np.ascontiguousarray(vertices, dtype=VERTEX)
+    d = np.ascontiguousarray(meshlet_data, dtype="<u4")
+    ml = np.array(meshlets, dtype=MESHLET).copy()
+    lib().orc_build_meshlet_cones(_ptr(v), _ptr(d), _ptr(ml), C.c_uint64(len(ml)))
+    return ml
+
+
 def create_globals(eye=(2.0, 2.0, 2.0), centre=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0), fov_deg=45.0, z_near=0.1,
                    width=800, height=600, flip_y=True, meshlet_count=0):
     g = np.zeros(1, dtype=GLOBALS)

@@ -441,6 +441,11 @@ void orc_build_meshlet_cone(const mcull_vertex *vertices, const uint32_t *meshle
 }
 
 /* createMeshlets: Engine.cpp:548-628. */
+void orc_build_meshlet_cones(const mcull_vertex *vertices, const uint32_t *meshlet_data,
+                             mcull_meshlet *meshlets, uint64_t count) {
+    for (uint64_t i = 0; i < count; i++) orc_build_meshlet_cone(vertices, meshlet_data, &meshlets[i]);
+}
+
 void orc_create_meshlets(orc_mesh *m) {
     free(m->meshlets); free(m->meshlet_data);
     uint64_t tri_count = m->index_count / 3;

@@ -59,6 +59,9 @@ void orc_create_meshlets(orc_mesh *m);
 /* buildMeshletCon alone, from the packed meshletData block of one meshlet. */
 void orc_build_meshlet_cone(const mcull_vertex *vertices, const uint32_t *meshlet_data,
                             mcull_meshlet *meshlet);
+/* the same over an array of meshlets, in order, one thread (the loop of Engine.cpp:585,625) */
+void orc_build_meshlet_cones(const mcull_vertex *vertices, const uint32_t *meshlet_data,
+                             mcull_meshlet *meshlets, uint64_t count);
 /* utils.hpp:94-99 (round-to-nearest-even float -> binary16). */
 uint16_t orc_float_to_half(float f);
 

@@ -95,6 +95,12 @@ def _rank_main(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "cmds_%d.npy" % rank), cmds_all.numpy())
     np.save(os.path.join(out_dir, "totals_%d.npy" % rank), totals_all.numpy())
     np.save(os.path.join(out_dir, "list_%d.npy" % rank), r.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4"))
+    # optional third step: the packed global list (drawIDs made global before the gather)
+    cap = len(ml) * (n_inst // world + 1)
+    lst = torch.zeros((cap, 2), dtype=torch.int32)
+    lst[: r.total] = torch.from_numpy((r.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4")).view("<i4"))
+    packed = D.gather_visible_lists(lst, totals_all)
+    np.save(os.path.join(out_dir, "packed_%d.npy" % rank), packed.numpy().view("<u4"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -118,6 +124,8 @@ def test_two_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten):
         assert int(totals.sum()) == ref.total
     glob = np.concatenate([np.load(tmp_path / ("list_%d.npy" % r)) for r in range(world)])
     assert np.array_equal(glob, ref.list.view("<u4").reshape(-1, 2))
+    for rank in range(world):  # the packed list every rank holds after the optional list gather
+        assert np.array_equal(np.load(tmp_path / ("packed_%d.npy" % rank)), glob)
 
 
 def test_cpp_wrapper_compiles_and_throws_like_vk_check(tmp_path, mc):

@@ -226,9 +226,15 @@ int main(int argc, char **argv) {
         auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
         timeit("ordered: cull_mask<3,4,nt> + compact<nt> + counter reset", [&] {
             hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
-            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total);
+            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 4), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 4u);
             zero_tc();
         });
+        // the scatter pass alone on the counters of one cull pass: workgroups per 256-group tile
+        hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc);
+        timeit("compact<nt> alone, 1 workgroup per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u); });
+        timeit("compact<nt> alone, 2 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 2), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 2u); });
+        timeit("compact<nt> alone, 4 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 4), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 4u); });
+        zero_tc();
         timeit("single pass: one atomic per wavefront", [&] {
             CK(hipMemsetAsync(total, 0, 8)); CK(hipMemsetAsync(inst_count, 0, (size_t)(n_inst + 1) * 4));
             hipLaunchKernelGGL((cull_atomic_kernel<3, false>), dim3(tiles), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, list, cap, inst_count, total, (uint64_t *)nullptr);

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(kBlock) void super_sum_kernel(const uint32_t *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered, pass 2: scatter.  One workgroup per 256-group tile.  Its list offset is the number of
+// ordered, pass 2: scatter.  `split` workgroups per 256-group tile (each redoes the tile's scan and
+// writes the entries of 256/split consecutive groups; the launcher uses 1, larger values exist for
+// the design-evidence benchmark).  A tile's list offset is the number of
 // visible pairs in all lower tiles: the sum of the lower tile counters (read from L2), or, for
 // very large scenes, of the lower super-tile sums plus the lower counters of its own super-tile.  Then one group per
 // thread for the in-tile scan, and one group per wave-iteration for the stores (lane l owns bit l,
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const uint32_t *__restrict__ super_counts, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
-    unsigned long long *__restrict__ total) {
+    unsigned long long *__restrict__ total, uint32_t split) {
     __shared__ uint64_t s_word[kBlock];
     __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
     __shared__ uint32_t s_wave[kWaves];
@@ -286,22 +288,24 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     __shared__ unsigned long long s_stage[kRoundGroups * 64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile_idx = blockIdx.x / split, part_idx = blockIdx.x - tile_idx * split;
+    const uint32_t round_span = kTileGroups / split;  // groups whose entries this workgroup writes
     unsigned long long part = 0;
     if (super_counts) {
-        const uint32_t super = blockIdx.x / kSuperTiles;
+        const uint32_t super = tile_idx / kSuperTiles;
         for (uint32_t j = threadIdx.x; j < super; j += kBlock) part += super_counts[j];
         const uint32_t j = super * kSuperTiles + threadIdx.x;  // kSuperTiles == kBlock
-        if (j < blockIdx.x) part += tile_counts[j];
+        if (j < tile_idx) part += tile_counts[j];
     } else {
-        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) part += tile_counts[j];
+        for (uint32_t j = threadIdx.x; j < tile_idx; j += kBlock) part += tile_counts[j];
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if (lane == 0) s_sum[wave] = part;
     __syncthreads();
     const unsigned long long running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + tile_counts[blockIdx.x];
-    const uint32_t tile = blockIdx.x * kTileGroups;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + tile_counts[tile_idx];
+    const uint32_t tile = tile_idx * kTileGroups;
     const uint32_t g_end = min(tile + kTileGroups, n_groups);
     const uint32_t g = tile + threadIdx.x;
     uint64_t word = 0;
@@ -325,14 +329,14 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     s_inst[threadIdx.x] = inst;
     s_first[threadIdx.x] = first;
     // firstTask of an instance = list offset of its first group (exclusive scan in instance order)
-    if (g < g_end && is_first_group) inst_first[inst] = (uint32_t)(running + excl);
+    if (g < g_end && is_first_group && threadIdx.x / round_span == part_idx) inst_first[inst] = (uint32_t)(running + excl);
     __syncthreads();
     const uint32_t n_tile = g_end - tile;
     // The surviving entries are first placed in LDS (each group's slots are contiguous, lane l owns
     // bit l), kRoundGroups groups at a time, and then streamed out linearly with aligned 16-byte
     // stores: whole cache lines instead of one partial, unaligned run per group.
     const uint32_t base_parity = (uint32_t)(reinterpret_cast<uintptr_t>(list) >> 3) & 1u;
-    for (uint32_t gbeg = 0; gbeg < n_tile; gbeg += kRoundGroups) {
+    for (uint32_t gbeg = part_idx * round_span; gbeg < min(n_tile, (part_idx + 1u) * round_span); gbeg += kRoundGroups) {
         const uint32_t round_off = s_off[gbeg];
         const uint32_t round_end = (gbeg + kRoundGroups < n_tile) ? s_off[gbeg + kRoundGroups] : tile_total;
         const uint32_t n_r = round_end - round_off;
@@ -569,9 +573,13 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st) {
-    const uint32_t grid = tile_count_for(s.n_groups);
+    const uint32_t tiles = tile_count_for(s.n_groups);
+    // one workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
+    // the tile scan) measured 118 / 152 us against 107 us for the 100 M-pair scene
+    const uint32_t split = 1u;
+    const uint32_t grid = tiles * split;
     if (super_counts) {
-        hipLaunchKernelGGL(super_sum_kernel, dim3(super_count_for(s.n_groups)), dim3(kBlock), 0, st, tile_counts, grid,
+        hipLaunchKernelGGL(super_sum_kernel, dim3(super_count_for(s.n_groups)), dim3(kBlock), 0, st, tile_counts, tiles,
                            super_counts);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -579,11 +587,11 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
     if (streaming)
         hipLaunchKernelGGL(compact_kernel<true>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, super_counts,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
-                           (unsigned long long *)total);
+                           (unsigned long long *)total, split);
     else
         hipLaunchKernelGGL(compact_kernel<false>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, super_counts,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
-                           (unsigned long long *)total);
+                           (unsigned long long *)total, split);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ struct mcull_ctx {
     DevBuf aos, cone, sphere, vertices, mdata, transforms, xf_scale, ranges, group_base, group_rec;
     uint64_t n_meshlets = 0, n_vertices = 0, n_words = 0, n_instances = 0;
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
+    bool geometry_checked = false;  // the uploaded meshlets index only inside the uploaded geometry (host check done)
     uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
 
     // Hi-Z
@@ -257,6 +258,7 @@ int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t 
                                            (float4 *)c->sphere.p, c->stream));
     c->n_meshlets = count;
     c->have_aos = true;
+    c->geometry_checked = false;
     c->have_bounds = true;
     c->last.valid = false;
     return MCULL_OK;
@@ -302,6 +304,7 @@ int mcull_upload_geometry(mcull_ctx *c, const mcull_vertex *vertices, uint64_t v
     c->n_vertices = vertex_count;
     c->n_words = word_count;
     c->have_geometry = true;
+    c->geometry_checked = false;
     return MCULL_OK;
 }
 
@@ -311,8 +314,9 @@ int mcull_compute_bounds(mcull_ctx *c) {
     if (!c->have_geometry) return fail(c, MCULL_E_STATE, "mcull_upload_geometry has not been called");
     HIPCHK(c, hipSetDevice(c->device));
     // Host-side shape check: every meshlet's block must lie inside meshletData and every global
-    // vertex id inside the vertex array; the kernel indexes without bounds checks.
-    {
+    // vertex id inside the vertex array; the kernel indexes without bounds checks.  Done once per
+    // upload (the kernel rewrites only cone/apex/radius, never the fields checked here).
+    if (!c->geometry_checked) {
         std::vector<mcull_meshlet> ml(c->n_meshlets);
         std::vector<uint32_t> md(c->n_words);
         HIPCHK(c, hipMemcpyAsync(ml.data(), c->aos.p, c->n_meshlets * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
@@ -331,6 +335,7 @@ int mcull_compute_bounds(mcull_ctx *c) {
                 if (loc[t] >= m.vertexCount)
                     return fail(c, MCULL_E_INVALID, "meshlet %llu: local index out of range", (unsigned long long)i);
         }
+        c->geometry_checked = true;
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_bounds((const mcull_vertex *)c->vertices.p, (const uint32_t *)c->mdata.p,

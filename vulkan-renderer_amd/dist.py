@@ -41,3 +41,32 @@ def gather_draw_list(total_local, cmds_local, rebase, group=None):
     cmds_all = torch.empty((world * cmds_local.shape[0], 2), dtype=cmds_local.dtype, device=cmds_local.device)
     dist.all_gather_into_tensor(cmds_all, cmds_local, group=group)
     return totals_all, cmds_all
+
+
+def gather_visible_lists(list_local, totals_all, out=None, group=None):
+    """Optional third step: one global visible list on every rank.  list_local: int32 tensor
+    [capacity, 2] whose first totals_all[rank] rows are this rank's (drawID, meshletID) entries with
+    rank-local drawIDs; totals_all: the gathered counts.  The shards differ in length, so every rank
+    contributes max(totals_all) rows (one host read of the counts) and the padding is dropped when
+    the shards are packed at their scanned offsets — the offsets the rebased firstTask values refer
+    to.  Returns an int32 tensor [sum(totals_all), 2]; `out`, when given, must hold at least that
+    many rows and receives the packed list (its first sum rows are returned).
+    Traffic per rank: world * max(totals) * 8 bytes received; over xGMI this is link-bound and costs
+    more than the cull itself, so a frame loop that can address per-rank lists should skip it."""
+    world = dist.get_world_size(group)
+    counts = [int(x) for x in totals_all.cpu().tolist()]
+    pad = max(max(counts), 1)
+    if list_local.shape[0] < pad:
+        raise ValueError("list_local holds %d rows, the largest shard has %d" % (list_local.shape[0], pad))
+    staged = torch.empty((world * pad, 2), dtype=list_local.dtype, device=list_local.device)
+    dist.all_gather_into_tensor(staged, list_local[:pad].contiguous(), group=group)
+    total = sum(counts)
+    if out is None:
+        out = torch.empty((max(total, 1), 2), dtype=list_local.dtype, device=list_local.device)
+    elif out.shape[0] < total:
+        raise ValueError("out holds %d rows, %d needed" % (out.shape[0], total))
+    pos = 0
+    for r, c in enumerate(counts):
+        out[pos:pos + c] = staged[r * pad:r * pad + c]
+        pos += c
+    return out[:total]
