@@ -36,6 +36,7 @@ extern "C" {
 #define MCULL_E_CAPACITY (-3) /* visible list larger than the output capacity         */
 #define MCULL_E_STATE (-4)    /* a required upload / build has not happened yet       */
 #define MCULL_E_NOMEM (-5)    /* allocation failed                                    */
+#define MCULL_E_IO (-6)       /* a scene file could not be opened, read or written    */
 
 /* ------------------------------------------------------------- layout contract   */
 
@@ -122,17 +123,28 @@ typedef struct mcull_task_payload {
                                        per-instance taskCount exact, firstTask = 0 for every draw */
 #define MCULL_COMPACT_BLOCK_ATOMIC 2 /* single pass, one atomic per workgroup batch; as above     */
 
-/* indirect-command form written by mcull_cull / mcull_rebase_commands: the reference's NV record
- * {taskCount = visible_i, firstTask} - one mesh workgroup per surviving meshlet, reading
- * list[firstTask + gl_WorkGroupID.x] (other values are reserved). */
+/* indirect-command form written by mcull_cull / mcull_rebase_commands.
+ * NV_MESHLETS: the reference's record (VkDrawMeshTasksIndirectCommandNV, Engine.hpp:102-105)
+ *   {taskCount = visible_i, firstTask} - one mesh workgroup per surviving meshlet, reading
+ *   list[firstTask + gl_WorkGroupID.x].  8 bytes.
+ * EXT_GROUPS: the three-word VkDrawMeshTasksIndirectCommandEXT form {groupCountX = visible_i,
+ *   groupCountY = 1, groupCountZ = 1} (12 bytes) for a frontend on VK_EXT_mesh_shader; that record
+ *   has no firstTask, so the mesh stage reads list[first_task[gl_DrawID] + gl_WorkGroupID.x] with
+ *   first_task from mcull_cull_result.  The reference itself only uses the NV form. */
 #define MCULL_CMD_NV_MESHLETS 0
+#define MCULL_CMD_EXT_GROUPS 1
+
+/* VkDrawMeshTasksIndirectCommandEXT as written for MCULL_CMD_EXT_GROUPS. 12 bytes. */
+typedef struct mcull_mesh_tasks_cmd_ext {
+    uint32_t groupCountX, groupCountY, groupCountZ;
+} mcull_mesh_tasks_cmd_ext;
 
 typedef struct mcull_cull_params {
     uint32_t tests;          /* MCULL_TEST_* bits                                      */
     uint32_t compaction;     /* MCULL_COMPACT_*                                        */
     uint32_t hiz_view;       /* which pyramid slot the Hi-Z test samples               */
-    uint32_t cmd_form;       /* MCULL_CMD_NV_MESHLETS                                  */
-    uint32_t cmd_stride;     /* bytes between commands; 0 -> 8                         */
+    uint32_t cmd_form;       /* MCULL_CMD_NV_MESHLETS or MCULL_CMD_EXT_GROUPS          */
+    uint32_t cmd_stride;     /* bytes between commands; 0 -> the record size (8 / 12)  */
     uint32_t cmd_offset;     /* byte offset of the command in a record; 28/20 = DrawIndirect */
     uint32_t write_mask;     /* non-zero: keep the 1-bit-per-pair visibility mask      */
     uint32_t reserved;
@@ -150,6 +162,8 @@ typedef struct mcull_cull_result {
     const uint64_t *mask;        /* device pointer, one 64-bit word per 64-meshlet group, or NULL */
     uint64_t n_groups;           /* number of 64-meshlet groups (mask words)           */
     uint64_t n_pairs;            /* meshlet-instances tested                           */
+    const uint32_t *first_task;  /* device pointer, one list offset per instance (defined for instances
+                                    that own meshlets), ordered compaction only, else NULL; rank-local */
 } mcull_cull_result;
 
 typedef struct mcull_ctx mcull_ctx;
@@ -264,6 +278,37 @@ int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
 int mcull_enable_timing(mcull_ctx *ctx, int enable);
 /* Milliseconds between the two timestamps of the last timed call. Synchronous. */
 int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
+
+/* ------------------------------------------------------------------ scene cache  */
+
+/* A scene file is the on-disk form of the arrays the path consumes - Engine.hpp:215-218
+ * (vertices, indices, meshlets, meshletData) plus the per-instance meshlet ranges - so the
+ * load-time pipeline of Engine.cpp:243-628 (loadModel, optimizeGeometry, createMeshlets) runs once
+ * per asset.  The reference has no such cache: it rebuilds everything at every start
+ * (Engine.cpp:16-17).  Little-endian, checksummed (FNV-1a-64 over the payload); these calls are
+ * host code and need no context or GPU, except mcull_scene_upload. */
+typedef struct mcull_scene_counts {
+    uint64_t vertex_count, index_count, meshlet_data_words, meshlet_count, range_count;
+    uint64_t checksum;
+} mcull_scene_counts;
+
+/* Any array may be empty (count 0).  MCULL_E_IO when the file cannot be written (a partial file
+ * is removed). */
+int mcull_scene_save(const char *path, const mcull_vertex *vertices, uint64_t vertex_count,
+                     const uint32_t *indices, uint64_t index_count, const uint32_t *meshlet_data,
+                     uint64_t meshlet_data_words, const mcull_meshlet *meshlets, uint64_t meshlet_count,
+                     const uint32_t *range_offset, const uint32_t *range_count, uint64_t n_ranges);
+/* Header only: the counts a caller needs to size its arrays.  MCULL_E_IO / MCULL_E_INVALID (not
+ * a scene file, unknown version, inconsistent sizes). */
+int mcull_scene_info(const char *path, mcull_scene_counts *out);
+/* Reads every section into caller-allocated arrays sized from mcull_scene_info (a NULL pointer
+ * skips that section).  MCULL_E_INVALID when the checksum does not match (the outputs then hold
+ * unverified bytes), MCULL_E_IO on a short read. */
+int mcull_scene_load(const char *path, mcull_vertex *vertices, uint32_t *indices, uint32_t *meshlet_data,
+                     mcull_meshlet *meshlets, uint32_t *range_offset, uint32_t *range_count);
+/* mcull_scene_load + mcull_upload_meshlets + mcull_upload_geometry + mcull_set_instance_ranges
+ * (ranges are cleared when the file holds none). */
+int mcull_scene_upload(mcull_ctx *ctx, const char *path);
 
 #ifdef __cplusplus
 }

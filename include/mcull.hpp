@@ -40,11 +40,12 @@ using Meshlet = mcull_meshlet;
 using Globals = mcull_globals;
 using Transform = mcull_transform;
 using DrawMeshTasksIndirectCommandNV = mcull_mesh_tasks_cmd;
+using DrawMeshTasksIndirectCommandEXT = mcull_mesh_tasks_cmd_ext;
 using DrawIndirect = mcull_draw_indirect;
 using Visible = mcull_visible;
 
 static_assert(sizeof(Vertex) == 24 && sizeof(Meshlet) == 48 && sizeof(Globals) == 212 && sizeof(Transform) == 64 &&
-                  sizeof(DrawMeshTasksIndirectCommandNV) == 8 && sizeof(DrawIndirect) == 28 && sizeof(Visible) == 8,
+                  sizeof(DrawMeshTasksIndirectCommandNV) == 8 && sizeof(DrawMeshTasksIndirectCommandEXT) == 12 && sizeof(DrawIndirect) == 28 && sizeof(Visible) == 8,
               "layout contract of shaders/common.h / Engine.hpp");
 
 class Culler {

@@ -246,6 +246,78 @@ def test_errors(mc, kitten, config1):
     ctx.close()
 
 
+def test_ext_command_form(mc, O, ctx, kitten, config1):
+    """MCULL_CMD_EXT_GROUPS: {groupCountX = visible_i, 1, 1} records (12 bytes, or embedded at a
+    caller-chosen stride/offset) plus the per-instance list offsets the EXT record has no room for."""
+    import ctypes
+
+    g, t = config1["globals"], config1["transforms"]
+    n = len(t)
+    ref = O.cull_scene(O.View(g), t, kitten["meshlets"], tests=3)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    for stride, offset in ((0, 0), (32, 16)):
+        r = ctx.cull(g, tests=3, cmd_form=mc.CMD_EXT_GROUPS, cmd_stride=stride, cmd_offset=offset)
+        st = stride or 12
+        raw = ctx.download_commands(n, st).reshape(n, st)
+        cmds = raw[:, offset:offset + 12].copy().view(mc.CMD_EXT).reshape(-1)
+        assert np.array_equal(cmds["groupCountX"], ref.commands["taskCount"])
+        assert (cmds["groupCountY"] == 1).all() and (cmds["groupCountZ"] == 1).all()
+        if st > 12:  # bytes of the record outside the command stay zero
+            rest = np.delete(raw, np.s_[offset:offset + 12], axis=1)
+            assert not rest.any()
+        assert r.first_task
+        first = np.zeros(n, dtype="<u4")
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        ctx.synchronize()
+        assert hip.hipMemcpy(ctypes.c_void_p(first.ctypes.data), ctypes.c_void_p(r.first_task), ctypes.c_size_t(n * 4), 2) == 0
+        assert np.array_equal(first, ref.commands["firstTask"])
+        assert ctx.download_list().tobytes() == ref.list.tobytes()
+    with pytest.raises(mc.McullError):  # nothing to rebase in an EXT record
+        ctx.rebase_commands(None, 0)
+    with pytest.raises(mc.McullError):  # the 12-byte record does not fit an 8-byte stride
+        ctx.cull(g, tests=3, cmd_form=mc.CMD_EXT_GROUPS, cmd_stride=8)
+    r = ctx.cull(g, tests=3, compaction=1, cmd_form=mc.CMD_EXT_GROUPS)
+    assert not r.first_task
+    cmds = ctx.download_commands(n, 12).view(mc.CMD_EXT)
+    assert np.array_equal(cmds["groupCountX"], ref.commands["taskCount"])
+    ctx.cull(g, tests=3)  # back to the NV form for whoever shares the context
+
+
+def test_scene_cache_upload(tmp_path, mc, O, ctx, kitten, bunny, H):
+    """A scene written to the cache file and uploaded from it culls exactly like the arrays it was
+    written from (mixed meshes through ranges), and its bounds can be recomputed on the GPU."""
+    meshlets = np.concatenate([kitten["meshlets"], bunny["meshlets"]])
+    data = np.concatenate([kitten["meshlet_data"], bunny["meshlet_data"]])
+    nk, nb = len(kitten["meshlets"]), len(bunny["meshlets"])
+    n = 200
+    t = H.update_transforms(n)
+    off = np.where(np.arange(n) % 2 == 0, 0, nk).astype("<u4")
+    cnt = np.where(np.arange(n) % 2 == 0, nk, nb).astype("<u4")
+    path = tmp_path / "scene.mcs"
+    mc.save_scene(path, kitten["vertices"], None, kitten["meshlet_data"], kitten["meshlets"])
+    ctx.upload_scene(path)  # no ranges in the file: uniform meshlet count, kitten only
+    ctx.upload_transforms(t)
+    g = H.create_globals(meshlet_count=nk)
+    ref = O.cull_scene(O.View(g), t, kitten["meshlets"], tests=3)
+    ctx.cull(g, tests=3)
+    assert ctx.download_list().tobytes() == ref.list.tobytes()
+    ctx.compute_bounds()
+    assert ctx.download_meshlets(nk).tobytes() == kitten["meshlets"].tobytes()
+    mc.save_scene(path, None, None, data, meshlets, off, cnt)  # mixed scene with ranges, no vertices
+    ctx.upload_scene(path)
+    g = H.create_globals(meshlet_count=0)
+    ref = O.cull_scene(O.View(g), t, meshlets, ranges=(off, cnt), tests=3)
+    ctx.cull(g, tests=3, write_mask=True)
+    assert np.array_equal(ctx.download_mask(), ref.mask)
+    check_against_oracle(mc, ctx, ref, n, 0)
+    with pytest.raises(mc.McullError) as e:
+        ctx.upload_scene(tmp_path / "missing.mcs")
+    assert e.value.status == mc.E_IO
+    ctx.set_instance_ranges(None, None)
+
+
 def test_rebase_commands(mc, O, ctx, kitten, config1):
     """mcull_rebase_commands: firstTask += sum of the lower ranks' visible counts, read from a device
     array of gathered totals (the multi-GPU hand-off); taskCount unchanged; idempotent per call."""

@@ -41,11 +41,12 @@ DRAW_INDIRECT = np.dtype(
 VISIBLE = np.dtype([("drawID", "<u4"), ("meshletID", "<u4")])
 TASK_PAYLOAD = np.dtype([("meshletIndices", "<u4", 32), ("drawID", "<u4"), ("taskCount", "<u4")])
 
-OK, E_INVALID, E_HIP, E_CAPACITY, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5
+OK, E_INVALID, E_HIP, E_CAPACITY, E_STATE, E_NOMEM, E_IO = 0, -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 TEST_FRUSTUM, TEST_CONE, TEST_HIZ, TEST_ALL = 1, 2, 4, 7
 COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
-CMD_NV_MESHLETS = 0
+CMD_NV_MESHLETS, CMD_EXT_GROUPS = 0, 1
+CMD_EXT = np.dtype([("groupCountX", "<u4"), ("groupCountY", "<u4"), ("groupCountZ", "<u4")])
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
 
 # every symbol include/mcull.h declares
@@ -56,7 +57,7 @@ ABI_SYMBOLS = [
     "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
     "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
     "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_enable_timing",
-    "mcull_last_kernel_ms",
+    "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload",
 ]
 
 
@@ -69,7 +70,7 @@ class CullParams(C.Structure):
 
 class CullResult(C.Structure):
     _fields_ = [("list", C.c_void_p), ("commands", C.c_void_p), ("total", C.c_void_p), ("mask", C.c_void_p),
-                ("n_groups", C.c_uint64), ("n_pairs", C.c_uint64)]
+                ("n_groups", C.c_uint64), ("n_pairs", C.c_uint64), ("first_task", C.c_void_p)]
 
 
 def _sig(name, restype, argtypes):
@@ -108,6 +109,17 @@ _sig("mcull_enable_timing", _I, [_P, _I])
 _sig("mcull_last_kernel_ms", _I, [_P, C.POINTER(C.c_float)])
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("vertex_count", C.c_uint64), ("index_count", C.c_uint64), ("meshlet_data_words", C.c_uint64),
+                ("meshlet_count", C.c_uint64), ("range_count", C.c_uint64), ("checksum", C.c_uint64)]
+
+
+_sig("mcull_scene_save", _I, [C.c_char_p, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, _P, C.c_uint64])
+_sig("mcull_scene_info", _I, [C.c_char_p, C.POINTER(SceneInfo)])
+_sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
+_sig("mcull_scene_upload", _I, [_P, C.c_char_p])
+
+
 class McullError(RuntimeError):
     def __init__(self, status, text):
         RuntimeError.__init__(self, "%s: %s" % (lib.mcull_status_string(status).decode(), text))
@@ -129,6 +141,43 @@ def hiz_layout(width, height):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _scene_chk(rc, path):
+    if rc != OK:
+        raise McullError(rc, "scene file %s" % path)
+
+
+def save_scene(path, vertices=None, indices=None, meshlet_data=None, meshlets=None, range_offset=None, range_count=None):
+    """Write the scene cache file (host code; needs no GPU).  Missing arrays are stored empty."""
+    v = np.ascontiguousarray(vertices if vertices is not None else np.zeros(0, VERTEX), dtype=VERTEX)
+    i = np.ascontiguousarray(indices if indices is not None else np.zeros(0, "<u4"), dtype="<u4")
+    d = np.ascontiguousarray(meshlet_data if meshlet_data is not None else np.zeros(0, "<u4"), dtype="<u4")
+    m = np.ascontiguousarray(meshlets if meshlets is not None else np.zeros(0, MESHLET), dtype=MESHLET)
+    ro = np.ascontiguousarray(range_offset if range_offset is not None else np.zeros(0, "<u4"), dtype="<u4")
+    rc = np.ascontiguousarray(range_count if range_count is not None else np.zeros(0, "<u4"), dtype="<u4")
+    if len(ro) != len(rc):
+        raise ValueError("range_offset and range_count differ in length")
+    _scene_chk(lib.mcull_scene_save(str(path).encode(), _np_ptr(v), len(v), _np_ptr(i), len(i), _np_ptr(d), len(d),
+                                    _np_ptr(m), len(m), _np_ptr(ro), _np_ptr(rc), len(ro)), path)
+
+
+def scene_info(path):
+    info = SceneInfo()
+    _scene_chk(lib.mcull_scene_info(str(path).encode(), C.byref(info)), path)
+    return info
+
+
+def load_scene(path):
+    """dict(vertices, indices, meshlet_data, meshlets, range_offset, range_count) read back and verified."""
+    info = scene_info(path)
+    out = {"vertices": np.zeros(info.vertex_count, VERTEX), "indices": np.zeros(info.index_count, "<u4"),
+           "meshlet_data": np.zeros(info.meshlet_data_words, "<u4"), "meshlets": np.zeros(info.meshlet_count, MESHLET),
+           "range_offset": np.zeros(info.range_count, "<u4"), "range_count": np.zeros(info.range_count, "<u4")}
+    _scene_chk(lib.mcull_scene_load(str(path).encode(), *[_np_ptr(out[k]) for k in
+                                                          ("vertices", "indices", "meshlet_data", "meshlets", "range_offset",
+                                                           "range_count")]), path)
+    return out
 
 
 class Context:
@@ -189,6 +238,10 @@ class Context:
     def compute_bounds(self):
         self._chk(lib.mcull_compute_bounds(self._h))
 
+    def upload_scene(self, path):
+        """Load a scene cache file and upload its meshlets, geometry and instance ranges."""
+        self._chk(lib.mcull_scene_upload(self._h, str(path).encode()))
+
     def download_meshlets(self, count):
         out = np.zeros(count, dtype=MESHLET)
         self._chk(lib.mcull_download_meshlets(self._h, _np_ptr(out), count))
@@ -239,7 +292,7 @@ class Context:
 
     # ---- cull + compact
     def cull(self, globals_, tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
-             cmd_stride=8, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
+             cmd_stride=0, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
              total_ptr=None):
         g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
         p = CullParams(tests, compaction, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)), 0,

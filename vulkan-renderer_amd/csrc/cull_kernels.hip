@@ -410,10 +410,14 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
         task_count = next_first - my_first;
         first_task = my_first + (uint32_t)base;
     }
-    (void)form;
     uint32_t *out = (uint32_t *)(commands + (size_t)i * stride + offset);
     out[0] = task_count;
-    out[1] = first_task;
+    if (form == MCULL_CMD_EXT_GROUPS) {  // {groupCountX, groupCountY, groupCountZ}
+        out[1] = 1u;
+        out[2] = 1u;
+    } else {
+        out[1] = first_task;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -190,6 +190,7 @@ const char *mcull_status_string(int status) {
         case MCULL_E_CAPACITY: return "MCULL_E_CAPACITY";
         case MCULL_E_STATE: return "MCULL_E_STATE";
         case MCULL_E_NOMEM: return "MCULL_E_NOMEM";
+        case MCULL_E_IO: return "MCULL_E_IO";
         default: return "MCULL_E_UNKNOWN";
     }
 }
@@ -505,12 +506,13 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     std::memset(&p, 0, sizeof p);
     if (params) p = *params;
     else { p.tests = MCULL_TEST_ALL; p.compaction = MCULL_COMPACT_ORDERED; }
-    if (p.cmd_stride == 0) p.cmd_stride = 8;
+    const uint32_t record = p.cmd_form == MCULL_CMD_EXT_GROUPS ? 12u : 8u;
+    if (p.cmd_stride == 0) p.cmd_stride = record;
     if (p.tests & ~MCULL_TEST_ALL) return fail(c, MCULL_E_INVALID, "unknown test bits 0x%x", p.tests);
     if (p.compaction > MCULL_COMPACT_BLOCK_ATOMIC) return fail(c, MCULL_E_INVALID, "unknown compaction %u", p.compaction);
-    if (p.cmd_form != MCULL_CMD_NV_MESHLETS) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
-    if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + 8u > p.cmd_stride)
-        return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+8 <= stride");
+    if (p.cmd_form > MCULL_CMD_EXT_GROUPS) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
+    if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + record > p.cmd_stride)
+        return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+%u <= stride", record);
     if ((p.tests & MCULL_TEST_HIZ) && (p.hiz_view >= MCULL_MAX_VIEWS || !c->hiz[p.hiz_view].built))
         return fail(c, MCULL_E_STATE, "Hi-Z test requested but no pyramid built for view %u", p.hiz_view);
     HIPCHK(c, hipSetDevice(c->device));
@@ -574,7 +576,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         const size_t bytes = (size_t)c->n_instances * p.cmd_stride;
         // bytes of a record outside the 8-byte command are never written by the kernels: the
         // context-owned buffer is zeroed whenever it is (re)allocated or its record layout changes
-        const uint64_t layout_key = ((uint64_t)p.cmd_stride << 32) | p.cmd_offset;
+        const uint64_t layout_key = ((uint64_t)p.cmd_stride << 32) | ((uint64_t)p.cmd_form << 24) | p.cmd_offset;
         const bool fresh = !c->commands.p || c->commands.cap < bytes || c->commands_layout != layout_key;
         if ((rc = ensure(c, c->commands, bytes))) return rc;
         if (fresh) HIPCHK(c, hipMemsetAsync(c->commands.p, 0, c->commands.cap, c->stream));
@@ -643,6 +645,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         result->mask = c->last.have_mask ? (const uint64_t *)c->mask.p : nullptr;
         result->n_groups = s.n_groups;
         result->n_pairs = n_pairs;
+        result->first_task = (p.compaction == MCULL_COMPACT_ORDERED && s.n_groups > 0) ? (const uint32_t *)c->inst_first.p : nullptr;
     }
     return MCULL_OK;
 }
@@ -651,6 +654,8 @@ int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t 
     if (!c) return MCULL_E_INVALID;
     if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result to rebase");
     if (!device_totals && rank) return fail(c, MCULL_E_INVALID, "device_totals is null");
+    if (c->last.lay.form == MCULL_CMD_EXT_GROUPS)
+        return fail(c, MCULL_E_INVALID, "EXT records carry no firstTask to rebase; offset first_task on the consumer side");
     HIPCHK(c, hipSetDevice(c->device));
     const bool ordered = c->last.compaction == MCULL_COMPACT_ORDERED && c->last.scene.n_groups > 0;
     HIPCHK(c, mcull::launch_emit_commands(c->last.scene, c->last.uniform_count,
