@@ -279,6 +279,24 @@ int mcull_enable_timing(mcull_ctx *ctx, int enable);
 /* Milliseconds between the two timestamps of the last timed call. Synchronous. */
 int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
 
+/* ------------------------------------------------------------------ depth source */
+
+/* Depth pre-pass stand-in (Engine.cpp:2397-2441 running shader.mesh:60-101 on the hardware
+ * rasteriser): rasterises every triangle of every meshlet in the LAST cull's visible list into a
+ * context-owned width x height float image, reverse-Z, nearest (largest) depth per pixel
+ * (Engine.cpp:975 GREATER_OR_EQUAL, clear 0 Engine.cpp:2404), back faces culled (Engine.cpp:961-962).
+ * `globals` supplies view/proj (gl_Position = proj*view*model*v, shader.mesh:73); the viewport is
+ * (0,0,width,height), depth 0..1 (Engine.cpp:2413-2420).  clear != 0 (or a size change) clears the
+ * image first; clear == 0 accumulates into the previous image.  Needs mcull_upload_meshlets and
+ * mcull_upload_geometry (not SoA-only scenes).  The image feeds mcull_hiz_build(..., MCULL_MEM_DEVICE):
+ * cull -> rasterise -> pyramid -> cull with MCULL_TEST_HIZ is the reference's two-phase frame
+ * (Engine.cpp:2381-2551) without the raster hardware.  Stream-ordered. */
+int mcull_depth_rasterize(mcull_ctx *ctx, const mcull_globals *globals, uint32_t width, uint32_t height, int clear);
+/* Device pointer and size of the image (valid until the next mcull_depth_rasterize with another size). */
+int mcull_depth_buffer(mcull_ctx *ctx, const float **device_ptr, uint32_t *width, uint32_t *height);
+/* Host copy, width*height floats. */
+int mcull_depth_download(mcull_ctx *ctx, float *out);
+
 /* ------------------------------------------------------------------ scene cache  */
 
 /* A scene file is the on-disk form of the arrays the path consumes - Engine.hpp:215-218

@@ -106,6 +106,21 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def rasterize_depth(vertices, meshlet_data, meshlets, transforms, visible, globals_, w, h, depth=None):
+    """Depth pre-pass stand-in over a visible list; returns the (h, w) reverse-Z image (accumulates
+    into `depth` when given)."""
+    v = np.ascontiguousarray(vertices, dtype=VERTEX)
+    d = np.ascontiguousarray(meshlet_data, dtype="<u4")
+    m = np.ascontiguousarray(meshlets, dtype=MESHLET)
+    t = np.ascontiguousarray(transforms, dtype=TRANSFORM)
+    lst = np.ascontiguousarray(visible, dtype=VISIBLE)
+    g = np.array(globals_, dtype=GLOBALS).reshape(1).copy()
+    out = np.zeros((h, w), dtype="<f4") if depth is None else np.ascontiguousarray(depth, dtype="<f4").copy()
+    lib().orc_rasterize_depth(_ptr(v), _ptr(d), _ptr(m), _ptr(t), _ptr(lst), C.c_uint64(len(lst)), _ptr(g),
+                              C.c_uint32(w), C.c_uint32(h), _ptr(out))
+    return out
+
+
 def fnv1a64(a):
     a = np.ascontiguousarray(a)
     return int(lib().orc_fnv1a64(_ptr(a), a.nbytes))

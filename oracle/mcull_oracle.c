@@ -97,6 +97,87 @@ static void m4_inverse(const float *m, float *out) {
             M(out, r, c) = M(cof, c, r) * inv_det;
 }
 
+/* ---------------------------------------------------------------- depth pre-pass stand-in
+ * The reference fills its depth buffer with the hardware rasteriser: depth pre-pass of
+ * Engine.cpp:2397-2441 running shader.mesh:60-101 (gl_Position = proj * view * model * vec4(v,1),
+ * evaluated left to right, i.e. ((proj*view)*model)*v), viewport (0,0,W,H) with depth 0..1
+ * (Engine.cpp:2413-2420), back faces culled with counter-clockwise front faces (Engine.cpp:961-962),
+ * depth test GREATER_OR_EQUAL on a buffer cleared to 0 (Engine.cpp:975, :2404).  Sub-pixel
+ * snapping and the exact interpolation of a hardware rasteriser are implementation-defined; the
+ * canonical software form used here: float edge functions at pixel centres, top-left fill rule,
+ * screen-space barycentric depth, fragments outside 0 <= z <= 1 dropped, triangles with a vertex
+ * at or behind the eye plane (w <= 0) dropped instead of clipped.  Every expression fixes its
+ * association order. */
+typedef struct { float x, y, z; int ok; } screen_vert;
+
+static screen_vert project_vertex(const float *mvp, const float *pos, float wf, float hf) {
+    screen_vert r;
+    float cx = ((M(mvp, 0, 0) * pos[0] + M(mvp, 0, 1) * pos[1]) + M(mvp, 0, 2) * pos[2]) + M(mvp, 0, 3);
+    float cy = ((M(mvp, 1, 0) * pos[0] + M(mvp, 1, 1) * pos[1]) + M(mvp, 1, 2) * pos[2]) + M(mvp, 1, 3);
+    float cz = ((M(mvp, 2, 0) * pos[0] + M(mvp, 2, 1) * pos[1]) + M(mvp, 2, 2) * pos[2]) + M(mvp, 2, 3);
+    float cw = ((M(mvp, 3, 0) * pos[0] + M(mvp, 3, 1) * pos[1]) + M(mvp, 3, 2) * pos[2]) + M(mvp, 3, 3);
+    r.ok = cw > 0.0f;
+    float nx = cx / cw, ny = cy / cw;
+    r.z = cz / cw;
+    r.x = (nx * 0.5f + 0.5f) * wf;   /* viewport transform, Engine.cpp:2413-2420 */
+    r.y = (ny * 0.5f + 0.5f) * hf;
+    return r;
+}
+
+/* edge a->b of a triangle that is counter-clockwise on a y-down screen: interior is e < 0 */
+static inline float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+static inline int edge_top_left(float ax, float ay, float bx, float by) {
+    float dx = bx - ax, dy = by - ay;
+    return dy > 0.0f || (dy == 0.0f && dx < 0.0f);
+}
+
+static void raster_triangle(screen_vert a, screen_vert b, screen_vert c, uint32_t w, uint32_t h, float *depth) {
+    if (!(a.ok && b.ok && c.ok)) return;
+    float area = (b.x - a.x) * (c.y - a.y) - (c.x - a.x) * (b.y - a.y);
+    if (!(area < 0.0f)) return;  /* back-facing, degenerate or NaN */
+    float minx = fminf(fminf(a.x, b.x), c.x), maxx = fmaxf(fmaxf(a.x, b.x), c.x);
+    float miny = fminf(fminf(a.y, b.y), c.y), maxy = fmaxf(fmaxf(a.y, b.y), c.y);
+    float x_lo = fmaxf(ceilf(minx - 0.5f), 0.0f), x_hi = fminf(floorf(maxx - 0.5f), (float)(w - 1));
+    float y_lo = fmaxf(ceilf(miny - 0.5f), 0.0f), y_hi = fminf(floorf(maxy - 0.5f), (float)(h - 1));
+    if (!(x_lo <= x_hi && y_lo <= y_hi)) return;
+    int tl0 = edge_top_left(b.x, b.y, c.x, c.y), tl1 = edge_top_left(c.x, c.y, a.x, a.y), tl2 = edge_top_left(a.x, a.y, b.x, b.y);
+    for (uint32_t py = (uint32_t)y_lo; py <= (uint32_t)y_hi; py++)
+        for (uint32_t px = (uint32_t)x_lo; px <= (uint32_t)x_hi; px++) {
+            float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+            float w0 = edge_fn(b.x, b.y, c.x, c.y, cx, cy);
+            float w1 = edge_fn(c.x, c.y, a.x, a.y, cx, cy);
+            float w2 = edge_fn(a.x, a.y, b.x, b.y, cx, cy);
+            if (!((w0 < 0.0f || (w0 == 0.0f && tl0)) && (w1 < 0.0f || (w1 == 0.0f && tl1)) && (w2 < 0.0f || (w2 == 0.0f && tl2))))
+                continue;
+            float z = ((w0 * a.z + w1 * b.z) + w2 * c.z) / area;
+            if (!(z >= 0.0f && z <= 1.0f)) continue;
+            uint32_t bits; memcpy(&bits, &z, 4);
+            bits &= 0x7fffffffu;  /* -0 -> +0 */
+            uint32_t cur; memcpy(&cur, &depth[(size_t)py * w + px], 4);
+            if (bits > cur) memcpy(&depth[(size_t)py * w + px], &bits, 4);  /* GREATER_OR_EQUAL on non-negative floats */
+        }
+}
+
+void orc_rasterize_depth(const mcull_vertex *vertices, const uint32_t *meshlet_data, const mcull_meshlet *meshlets,
+                         const mcull_transform *transforms, const mcull_visible *list, uint64_t count,
+                         const mcull_globals *g, uint32_t w, uint32_t h, float *depth) {
+    float vp[16];
+    m4_mul(g->proj, g->view, vp);
+    for (uint64_t e = 0; e < count; e++) {
+        const mcull_meshlet *m = &meshlets[list[e].meshletID];
+        float mvp[16];
+        m4_mul(vp, transforms[list[e].drawID].model, mvp);
+        const uint32_t *globals = meshlet_data + m->dataOffset;
+        const uint8_t *locals = (const uint8_t *)(globals + m->vertexCount);
+        screen_vert sv[64];
+        for (uint32_t i = 0; i < m->vertexCount; i++) sv[i] = project_vertex(mvp, &vertices[globals[i]].vx, (float)w, (float)h);
+        for (uint32_t t = 0; t < m->triangleCount; t++)
+            raster_triangle(sv[locals[3 * t]], sv[locals[3 * t + 1]], sv[locals[3 * t + 2]], w, h, depth);
+    }
+}
+
 uint64_t orc_fnv1a64(const void *data, uint64_t bytes) {
     const uint8_t *p = (const uint8_t *)data;
     uint64_t h = 1469598103934665603ull;

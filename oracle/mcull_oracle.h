@@ -150,6 +150,15 @@ int orc_cull_scene(const orc_scene *s, const orc_view *v, uint32_t tests, int th
 uint64_t orc_task_payloads(const orc_scene *s, const orc_view *v, uint32_t tests,
                            mcull_task_payload *out);
 
+/* ---------------------------------------------------------------- depth source      */
+
+/* Software stand-in for the depth pre-pass (Engine.cpp:2397-2441, shader.mesh:60-101): rasterises
+ * the triangles of the listed (drawID, meshletID) pairs into `depth` (h rows of w floats, reverse-Z,
+ * the caller clears it to 0), keeping the nearest (largest) depth per pixel. */
+void orc_rasterize_depth(const mcull_vertex *vertices, const uint32_t *meshlet_data, const mcull_meshlet *meshlets,
+                         const mcull_transform *transforms, const mcull_visible *list, uint64_t count,
+                         const mcull_globals *g, uint32_t w, uint32_t h, float *depth);
+
 /* ---------------------------------------------------------------- utilities         */
 uint64_t orc_fnv1a64(const void *data, uint64_t bytes);
 int orc_max_threads(void);

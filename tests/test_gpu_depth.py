@@ -1,0 +1,140 @@
+"""GPU parity of the depth pre-pass stand-in (mcull_depth_rasterize) and of the two-phase frame it
+enables: cull -> rasterise -> Hi-Z pyramid -> cull with the Hi-Z test.  Depth images bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype="<f4").view("<u4")
+
+
+def test_two_phase_frame_kitten(mc, O, ctx, kitten, config1):
+    """Config 1: phase 1 culls without Hi-Z, the survivors are rasterised, the pyramid is built from
+    that image on the device and phase 2 culls against it; every stage equals the oracle's."""
+    g, t = config1["globals"], config1["transforms"]
+    w, h = 800, 600
+    ml = kitten["meshlets"]
+    ref1 = O.cull_scene(O.View(g), t, ml, tests=3)
+    img_ref = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, ref1.list, g, w, h)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(ml)
+    ctx.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+    ctx.upload_transforms(t)
+    ctx.cull(g, tests=3)
+    ctx.depth_rasterize(g, w, h)
+    img = ctx.depth_download()
+    assert np.array_equal(_bits(img), _bits(img_ref)), "depth image must be bit-exact"
+    assert 0.01 < (img > 0).mean() < 0.95
+    ptr, dw, dh = ctx.depth_buffer()
+    assert (dw, dh) == (w, h)
+    ctx.hiz_build(ptr, view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+    pyr_ref = O.hiz_build(img_ref)
+    for a, b in zip(ctx.hiz_download(view=0), O.hiz_levels(pyr_ref, w, h)):
+        assert np.array_equal(_bits(a), _bits(b))
+    ref2 = O.cull_scene(O.View(g, pyr_ref, w, h), t, ml, tests=7)
+    ctx.cull(g, tests=7, hiz_view=0, write_mask=True)
+    assert np.array_equal(ctx.download_mask(), ref2.mask)
+    assert ctx.download_list().tobytes() == ref2.list.tobytes()
+    assert 0 < ref2.total <= ref1.total
+
+
+def test_large_triangles_accumulation_and_eye_plane(mc, O, ctx, kitten, H):
+    """Instances scaled up and pushed towards the camera: boxes of thousands of pixels (rasterised by
+    the whole wave), triangles crossing the eye plane (dropped), and a second pass accumulated into
+    the same image with clear = 0."""
+    w, h = 1920, 1080
+    ml = kitten["meshlets"]
+    n = 24
+    t = H.update_transforms(n)
+    model = t["model"].reshape(n, 4, 4).copy()      # [c][r]
+    rs = np.random.RandomState(4)
+    for i in range(n):
+        s = np.float32([1.0, 2.0, 4.0, 8.0][i % 4])
+        model[i, :3, :3] *= s
+        model[i, 3, :3] = (rs.uniform(-1.0, 1.0, 3) * [1.5, 1.5, 1.5] + [0.6, 0.6, 0.6]).astype("<f4")
+    t["model"] = model.reshape(n, 16)
+    g = H.create_globals(width=w, height=h, meshlet_count=len(ml))
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(ml)
+    ctx.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+    ctx.upload_transforms(t)
+    ref_a = O.cull_scene(O.View(g), t, ml, tests=1)          # frustum only: back faces reach the rasteriser
+    ctx.cull(g, tests=1)
+    ctx.depth_rasterize(g, w, h)
+    img_a = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, ref_a.list, g, w, h)
+    got_a = ctx.depth_download()
+    assert np.array_equal(_bits(got_a), _bits(img_a))
+    assert (img_a > 0).mean() > 0.2                          # the enlarged instances really fill the screen
+    # second pass from another camera accumulated into the same image
+    g2 = H.create_globals(eye=(3.0, -2.0, 2.5), width=w, height=h, meshlet_count=len(ml))
+    ref_b = O.cull_scene(O.View(g2), t, ml, tests=3)
+    ctx.cull(g2, tests=3)
+    ctx.depth_rasterize(g2, w, h, clear=False)
+    img_b = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, ref_b.list, g2, w, h, depth=img_a)
+    assert np.array_equal(_bits(ctx.depth_download()), _bits(img_b))
+    assert not np.array_equal(img_a, img_b)
+    # a different size reallocates and clears
+    ctx.depth_rasterize(g2, 320, 200, clear=False)
+    small = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, ref_b.list,
+                              H.create_globals(eye=(3.0, -2.0, 2.5), width=w, height=h, meshlet_count=len(ml)), 320, 200)
+    assert np.array_equal(_bits(ctx.depth_download()), _bits(small))
+
+
+def test_mixed_meshes_through_ranges(mc, O, ctx, kitten, bunny, H):
+    """The list's meshlet ids are global: kitten and bunny instances through per-instance ranges."""
+    w, h = 640, 480
+    nk, nb = len(kitten["meshlets"]), len(bunny["meshlets"])
+    bun = bunny["meshlets"].copy()
+    bun["dataOffset"] += len(kitten["meshlet_data"])
+    meshlets = np.concatenate([kitten["meshlets"], bun])
+    data = np.concatenate([kitten["meshlet_data"], bunny["meshlet_data"] + 0])
+    # bunny's global vertex ids are shifted behind kitten's vertices
+    nkv = len(kitten["vertices"])
+    data = data.copy()
+    for m in bun:
+        o, nv = int(m["dataOffset"]), int(m["vertexCount"])
+        data[o:o + nv] += nkv
+    verts = np.concatenate([kitten["vertices"], bunny["vertices"]])
+    n = 40
+    t = H.update_transforms(n)
+    off = np.where(np.arange(n) % 2 == 0, 0, nk).astype("<u4")
+    cnt = np.where(np.arange(n) % 2 == 0, nk, nb).astype("<u4")
+    g = H.create_globals(width=w, height=h, meshlet_count=0)
+    ctx.upload_meshlets(meshlets)
+    ctx.upload_geometry(verts, data)
+    ctx.upload_transforms(t)
+    ctx.set_instance_ranges(off, cnt)
+    ref = O.cull_scene(O.View(g), t, meshlets, ranges=(off, cnt), tests=3)
+    ctx.cull(g, tests=3)
+    ctx.depth_rasterize(g, w, h)
+    want = O.rasterize_depth(verts, data, meshlets, t, ref.list, g, w, h)
+    assert np.array_equal(_bits(ctx.depth_download()), _bits(want))
+    assert (want > 0).any()
+    ctx.set_instance_ranges(None, None)
+
+
+def test_depth_errors(mc, H, kitten, config1):
+    c = mc.Context(0)
+    g = config1["globals"]
+    with pytest.raises(mc.McullError) as e:
+        c.depth_rasterize(g, 64, 64)
+    assert e.value.status == mc.E_STATE                       # no cull yet
+    with pytest.raises(mc.McullError) as e:
+        c.depth_buffer()
+    assert e.value.status == mc.E_STATE
+    c.upload_meshlets(kitten["meshlets"])
+    c.upload_transforms(config1["transforms"][:4])
+    c.cull(g, tests=3)
+    with pytest.raises(mc.McullError) as e:
+        c.depth_rasterize(g, 64, 64)
+    assert e.value.status == mc.E_STATE                       # geometry not uploaded
+    c.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+    c.cull(g, tests=3)
+    with pytest.raises(mc.McullError) as e:
+        c.depth_rasterize(g, 0, 64)
+    assert e.value.status == mc.E_INVALID
+    c.depth_rasterize(g, 64, 64)
+    assert c.depth_download().shape == (64, 64)
+    c.close()

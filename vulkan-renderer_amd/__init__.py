@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
     "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
     "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_enable_timing",
-    "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload",
+    "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload", "mcull_depth_rasterize", "mcull_depth_buffer", "mcull_depth_download",
 ]
 
 
@@ -118,6 +118,9 @@ _sig("mcull_scene_save", _I, [C.c_char_p, _P, C.c_uint64, _P, C.c_uint64, _P, C.
 _sig("mcull_scene_info", _I, [C.c_char_p, C.POINTER(SceneInfo)])
 _sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
 _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
+_sig("mcull_depth_rasterize", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
+_sig("mcull_depth_buffer", _I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
+_sig("mcull_depth_download", _I, [_P, _P])
 
 
 class McullError(RuntimeError):
@@ -237,6 +240,23 @@ class Context:
 
     def compute_bounds(self):
         self._chk(lib.mcull_compute_bounds(self._h))
+
+    def depth_rasterize(self, globals_, width, height, clear=True):
+        """Rasterise the last cull's visible meshlets into the context's depth image."""
+        g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
+        self._chk(lib.mcull_depth_rasterize(self._h, _np_ptr(g), width, height, int(bool(clear))))
+
+    def depth_buffer(self):
+        """(device pointer, width, height) of the depth image."""
+        p, w, h = C.c_void_p(), _U32(), _U32()
+        self._chk(lib.mcull_depth_buffer(self._h, C.byref(p), C.byref(w), C.byref(h)))
+        return p.value, int(w.value), int(h.value)
+
+    def depth_download(self):
+        _, w, h = self.depth_buffer()
+        out = np.zeros((h, w), dtype="<f4")
+        self._chk(lib.mcull_depth_download(self._h, _np_ptr(out)))
+        return out
 
     def upload_scene(self, path):
         """Load a scene cache file and upload its meshlets, geometry and instance ranges."""

@@ -1,0 +1,168 @@
+// Depth source for the Hi-Z pyramid: a depth-only software rasteriser over the visible list.
+//
+// Stands in for the reference's depth pre-pass (Engine.cpp:2397-2441 running shader.mesh:60-101 on
+// the hardware rasteriser): gl_Position = ((proj*view)*model)*vec4(v,1), viewport (0,0,W,H) with
+// depth 0..1 (Engine.cpp:2413-2420), back faces culled with counter-clockwise front faces
+// (Engine.cpp:961-962), depth test GREATER_OR_EQUAL on a buffer cleared to 0 (Engine.cpp:975,:2404).
+// What a hardware rasteriser leaves implementation-defined is fixed here as: float edge functions
+// evaluated at pixel centres, top-left fill rule, screen-space barycentric depth, fragments outside
+// 0 <= z <= 1 dropped, triangles with a vertex at or behind the eye plane (w <= 0) dropped instead
+// of clipped.  Every expression fixes its association order (no fused multiply-add, correctly
+// rounded division), and the per-pixel result is a maximum, so the image is independent of the
+// order in which triangles arrive and equals a sequential evaluation bit for bit.
+//
+// One wave per visible (drawID, meshletID) entry: lane l projects local vertex l (a meshlet has at
+// most 64), triangles fetch their corners with lane shuffles, lane t rasterises triangle t and
+// t + 64.  Triangles whose pixel box exceeds kSmallBox pixels are rasterised by the whole wave, one
+// after another, so a single lane never walks a large box alone.  Depth is stored as the float's
+// bit pattern and merged with atomicMax (non-negative floats order like unsigned integers).
+#include "mcull_internal.h"
+
+namespace mcull {
+
+constexpr int kRasterBlock = 256;
+constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own
+
+struct RasterConst {
+    float vp[16];  // proj * view, column-major
+    float wf, hf;
+    uint32_t w, h;
+};
+
+struct Tri {
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+__device__ __forceinline__ bool edge_top_left(float ax, float ay, float bx, float by) {
+    const float dx = bx - ax, dy = by - ay;
+    return dy > 0.0f || (dy == 0.0f && dx < 0.0f);
+}
+
+// one pixel of one front-facing triangle (area < 0)
+__device__ __forceinline__ void raster_pixel(const Tri &t, float area, bool tl0, bool tl1, bool tl2, uint32_t px, uint32_t py,
+                                             uint32_t w, uint32_t *__restrict__ depth_bits) {
+    const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+    const float w0 = edge_fn(t.x1, t.y1, t.x2, t.y2, cx, cy);
+    const float w1 = edge_fn(t.x2, t.y2, t.x0, t.y0, cx, cy);
+    const float w2 = edge_fn(t.x0, t.y0, t.x1, t.y1, cx, cy);
+    if (!((w0 < 0.0f || (w0 == 0.0f && tl0)) && (w1 < 0.0f || (w1 == 0.0f && tl1)) && (w2 < 0.0f || (w2 == 0.0f && tl2)))) return;
+    const float z = ((w0 * t.z0 + w1 * t.z1) + w2 * t.z2) / area;
+    if (!(z >= 0.0f && z <= 1.0f)) return;
+    const uint32_t bits = __float_as_uint(z) & 0x7fffffffu;  // -0 -> +0
+    uint32_t *dst = depth_bits + (size_t)py * w + px;
+    if (bits > *dst) atomicMax(dst, bits);  // the plain read only filters; the atomic decides
+}
+
+__global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
+    const mcull_visible *__restrict__ list, const unsigned long long *__restrict__ total, uint64_t capacity,
+    const mcull_meshlet *__restrict__ meshlets, const uint32_t *__restrict__ meshlet_data,
+    const mcull_vertex *__restrict__ vertices, const float *__restrict__ transforms, RasterConst rc,
+    uint32_t *__restrict__ depth_bits) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kRasterBlock / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kRasterBlock / 64);
+    unsigned long long n = *total;
+    if (n > capacity) n = capacity;
+    for (uint64_t e = wave0; e < n; e += n_waves) {
+        const mcull_visible ent = list[e];
+        const mcull_meshlet *m = meshlets + ent.meshletID;
+        const uint32_t off = m->dataOffset, vc = m->vertexCount, tc = m->triangleCount;
+        // mvp = (proj*view) * model, the element sum in the order k = 0..3
+        const float *mdl = transforms + (size_t)ent.drawID * 16;
+        float mvp[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                mvp[4 * c + r] = ((rc.vp[r] * mdl[4 * c] + rc.vp[4 + r] * mdl[4 * c + 1]) + rc.vp[8 + r] * mdl[4 * c + 2]) +
+                                 rc.vp[12 + r] * mdl[4 * c + 3];
+        // lane l: local vertex l -> screen position
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        int ok = 0;
+        if (lane < vc) {
+            const mcull_vertex *v = vertices + meshlet_data[off + lane];
+            const float px = v->vx, py = v->vy, pz = v->vz;
+            const float cx = ((mvp[0] * px + mvp[4] * py) + mvp[8] * pz) + mvp[12];
+            const float cy = ((mvp[1] * px + mvp[5] * py) + mvp[9] * pz) + mvp[13];
+            const float cz = ((mvp[2] * px + mvp[6] * py) + mvp[10] * pz) + mvp[14];
+            const float cw = ((mvp[3] * px + mvp[7] * py) + mvp[11] * pz) + mvp[15];
+            ok = cw > 0.0f;
+            const float nx = cx / cw, ny = cy / cw;
+            sz = cz / cw;
+            sx = (nx * 0.5f + 0.5f) * rc.wf;
+            sy = (ny * 0.5f + 0.5f) * rc.hf;
+        }
+        const uint8_t *locals = reinterpret_cast<const uint8_t *>(meshlet_data + off + vc);
+        for (uint32_t base = 0; base < tc; base += 64u) {  // wave-uniform trip count
+            const uint32_t t = base + lane;
+            const bool valid = t < tc;
+            const uint32_t i0 = valid ? locals[3 * t] : 0u, i1 = valid ? locals[3 * t + 1] : 0u, i2 = valid ? locals[3 * t + 2] : 0u;
+            Tri tr;
+            tr.x0 = __shfl(sx, (int)i0); tr.y0 = __shfl(sy, (int)i0); tr.z0 = __shfl(sz, (int)i0);
+            tr.x1 = __shfl(sx, (int)i1); tr.y1 = __shfl(sy, (int)i1); tr.z1 = __shfl(sz, (int)i1);
+            tr.x2 = __shfl(sx, (int)i2); tr.y2 = __shfl(sy, (int)i2); tr.z2 = __shfl(sz, (int)i2);
+            const int all_ok = __shfl(ok, (int)i0) & __shfl(ok, (int)i1) & __shfl(ok, (int)i2);
+            const float area = (tr.x1 - tr.x0) * (tr.y2 - tr.y0) - (tr.x2 - tr.x0) * (tr.y1 - tr.y0);
+            bool draw = valid && all_ok && (area < 0.0f);  // front-facing, in front of the eye, not NaN
+            const float minx = fminf(fminf(tr.x0, tr.x1), tr.x2), maxx = fmaxf(fmaxf(tr.x0, tr.x1), tr.x2);
+            const float miny = fminf(fminf(tr.y0, tr.y1), tr.y2), maxy = fmaxf(fmaxf(tr.y0, tr.y1), tr.y2);
+            const float x_lo = fmaxf(ceilf(minx - 0.5f), 0.0f), x_hi = fminf(floorf(maxx - 0.5f), (float)(rc.w - 1u));
+            const float y_lo = fmaxf(ceilf(miny - 0.5f), 0.0f), y_hi = fminf(floorf(maxy - 0.5f), (float)(rc.h - 1u));
+            draw = draw && (x_lo <= x_hi) && (y_lo <= y_hi);
+            uint32_t bx = 0, by = 0, bw = 0, bh = 0;
+            if (draw) {
+                bx = (uint32_t)x_lo; by = (uint32_t)y_lo;
+                bw = (uint32_t)x_hi - bx + 1u; bh = (uint32_t)y_hi - by + 1u;
+            }
+            const bool tl0 = edge_top_left(tr.x1, tr.y1, tr.x2, tr.y2), tl1 = edge_top_left(tr.x2, tr.y2, tr.x0, tr.y0),
+                       tl2 = edge_top_left(tr.x0, tr.y0, tr.x1, tr.y1);
+            const uint64_t box = (uint64_t)bw * bh;
+            const bool small = draw && box <= kSmallBox;
+            if (small) {
+                for (uint32_t p = 0; p < (uint32_t)box; p++) {
+                    const uint32_t yy = p / bw, xx = p - yy * bw;
+                    raster_pixel(tr, area, tl0, tl1, tl2, bx + xx, by + yy, rc.w, depth_bits);
+                }
+            }
+            // large boxes: the whole wave walks one triangle at a time
+            uint64_t big = __ballot(draw && !small);
+            while (big) {
+                const int src = __builtin_ctzll(big);
+                big &= big - 1ull;
+                Tri b;
+                b.x0 = __shfl(tr.x0, src); b.y0 = __shfl(tr.y0, src); b.z0 = __shfl(tr.z0, src);
+                b.x1 = __shfl(tr.x1, src); b.y1 = __shfl(tr.y1, src); b.z1 = __shfl(tr.z1, src);
+                b.x2 = __shfl(tr.x2, src); b.y2 = __shfl(tr.y2, src); b.z2 = __shfl(tr.z2, src);
+                const float b_area = __shfl(area, src);
+                const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
+                const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
+                           t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
+                const uint64_t cells = (uint64_t)ow * oh;
+                for (uint64_t p = lane; p < cells; p += 64u) {
+                    const uint32_t yy = (uint32_t)(p / ow), xx = (uint32_t)(p - (uint64_t)yy * ow);
+                    raster_pixel(b, b_area, t0, t1, t2, ox + xx, oy + yy, rc.w, depth_bits);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
+                               const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
+                               const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
+                               hipStream_t st) {
+    RasterConst rc;
+    for (int i = 0; i < 16; i++) rc.vp[i] = vp[i];
+    rc.w = w; rc.h = h;
+    rc.wf = (float)w; rc.hf = (float)h;
+    // the entry count lives on the device: a fixed grid whose waves stride over the list
+    const uint32_t grid = 256 * 8;
+    hipLaunchKernelGGL(depth_raster_kernel, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
+                       capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth));
+    return hipGetLastError();
+}
+
+}  // namespace mcull

@@ -51,6 +51,8 @@ struct mcull_ctx {
     // Hi-Z
     HizSlot hiz[MCULL_MAX_VIEWS];
     DevBuf depth_staging, hiz_counter;
+    DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
+    uint32_t depth_w = 0, depth_h = 0;
     bool hiz_single_pass = true;
 
     // cull scratch + outputs
@@ -226,7 +228,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
                       &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->mask, &c->tile_counts, &c->super_counts,
-                      &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands};
+                      &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands, &c->depth};
     for (DevBuf *b : bufs) release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -309,35 +311,40 @@ int mcull_upload_geometry(mcull_ctx *c, const mcull_vertex *vertices, uint64_t v
     return MCULL_OK;
 }
 
-int mcull_compute_bounds(mcull_ctx *c) {
-    if (!c) return MCULL_E_INVALID;
+// Host-side shape check shared by the kernels that walk meshlet geometry: every meshlet's block
+// must lie inside meshletData, every global vertex id inside the vertex array and every local index
+// below the meshlet's vertex count; the kernels index without bounds checks.  Done once per upload
+// (the kernels rewrite only cone/apex/radius, never the fields checked here).
+static int check_geometry(mcull_ctx *c) {
     if (!c->have_aos) return fail(c, MCULL_E_STATE, "mcull_upload_meshlets has not been called");
     if (!c->have_geometry) return fail(c, MCULL_E_STATE, "mcull_upload_geometry has not been called");
-    HIPCHK(c, hipSetDevice(c->device));
-    // Host-side shape check: every meshlet's block must lie inside meshletData and every global
-    // vertex id inside the vertex array; the kernel indexes without bounds checks.  Done once per
-    // upload (the kernel rewrites only cone/apex/radius, never the fields checked here).
-    if (!c->geometry_checked) {
-        std::vector<mcull_meshlet> ml(c->n_meshlets);
-        std::vector<uint32_t> md(c->n_words);
-        HIPCHK(c, hipMemcpyAsync(ml.data(), c->aos.p, c->n_meshlets * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(md.data(), c->mdata.p, c->n_words * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (uint64_t i = 0; i < c->n_meshlets; i++) {
-            const mcull_meshlet &m = ml[i];
-            const uint64_t words = (uint64_t)m.vertexCount + ((uint64_t)m.triangleCount * 3 + 3) / 4;
-            if (m.vertexCount > 64 || m.triangleCount > 124 || (uint64_t)m.dataOffset + words > c->n_words)
-                return fail(c, MCULL_E_INVALID, "meshlet %llu: counts/dataOffset outside meshletData", (unsigned long long)i);
-            const uint8_t *loc = reinterpret_cast<const uint8_t *>(md.data() + m.dataOffset + m.vertexCount);
-            for (uint32_t v = 0; v < m.vertexCount; v++)
-                if (md[m.dataOffset + v] >= c->n_vertices)
-                    return fail(c, MCULL_E_INVALID, "meshlet %llu: vertex id out of range", (unsigned long long)i);
-            for (uint32_t t = 0; t < (uint32_t)m.triangleCount * 3; t++)
-                if (loc[t] >= m.vertexCount)
-                    return fail(c, MCULL_E_INVALID, "meshlet %llu: local index out of range", (unsigned long long)i);
-        }
-        c->geometry_checked = true;
+    if (c->geometry_checked) return MCULL_OK;
+    std::vector<mcull_meshlet> ml(c->n_meshlets);
+    std::vector<uint32_t> md(c->n_words);
+    HIPCHK(c, hipMemcpyAsync(ml.data(), c->aos.p, c->n_meshlets * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(md.data(), c->mdata.p, c->n_words * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t i = 0; i < c->n_meshlets; i++) {
+        const mcull_meshlet &m = ml[i];
+        const uint64_t words = (uint64_t)m.vertexCount + ((uint64_t)m.triangleCount * 3 + 3) / 4;
+        if (m.vertexCount > 64 || m.triangleCount > 124 || (uint64_t)m.dataOffset + words > c->n_words)
+            return fail(c, MCULL_E_INVALID, "meshlet %llu: counts/dataOffset outside meshletData", (unsigned long long)i);
+        const uint8_t *loc = reinterpret_cast<const uint8_t *>(md.data() + m.dataOffset + m.vertexCount);
+        for (uint32_t v = 0; v < m.vertexCount; v++)
+            if (md[m.dataOffset + v] >= c->n_vertices)
+                return fail(c, MCULL_E_INVALID, "meshlet %llu: vertex id out of range", (unsigned long long)i);
+        for (uint32_t t = 0; t < (uint32_t)m.triangleCount * 3; t++)
+            if (loc[t] >= m.vertexCount)
+                return fail(c, MCULL_E_INVALID, "meshlet %llu: local index out of range", (unsigned long long)i);
     }
+    c->geometry_checked = true;
+    return MCULL_OK;
+}
+
+int mcull_compute_bounds(mcull_ctx *c) {
+    if (!c) return MCULL_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_geometry(c)) return rc;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_bounds((const mcull_vertex *)c->vertices.p, (const uint32_t *)c->mdata.p,
                                    (mcull_meshlet *)c->aos.p, c->n_meshlets, (float4 *)c->cone.p, (float4 *)c->sphere.p,
@@ -733,6 +740,56 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
         HIPCHK(c, hipMemcpyAsync(out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return MCULL_OK;
+}
+
+// ------------------------------------------------------------------------------------ depth source
+
+int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, uint32_t height, int clear) {
+    if (!c) return MCULL_E_INVALID;
+    if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return fail(c, MCULL_E_INVALID, "depth size %ux%u", width, height);
+    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result to rasterise");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_geometry(c)) return rc;
+    // the list's meshlet ids index the AoS records: they must be the array the cull ran on
+    if (c->last.scene.cone_axis_w != (const float4 *)c->cone.p)
+        return fail(c, MCULL_E_STATE, "the last cull ran on adopted SoA bounds, not on the uploaded meshlets");
+    const size_t bytes = (size_t)width * height * 4;
+    const bool resized = c->depth_w != width || c->depth_h != height;
+    if (int rc = ensure(c, c->depth, bytes)) return rc;
+    c->depth_w = width;
+    c->depth_h = height;
+    if (clear || resized) HIPCHK(c, hipMemsetAsync(c->depth.p, 0, bytes, c->stream));  // clear value 0 (Engine.cpp:2404)
+    float vp[16];
+    mat4_mul(g->proj, g->view, vp);
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mcull::launch_depth_raster(c->last.list, (const uint64_t *)c->total_ptr, c->last.capacity,
+                                         (const mcull_meshlet *)c->aos.p, (const uint32_t *)c->mdata.p,
+                                         (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, vp, width,
+                                         height, (float *)c->depth.p, c->stream));
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
+    return MCULL_OK;
+}
+
+int mcull_depth_buffer(mcull_ctx *c, const float **device_ptr, uint32_t *width, uint32_t *height) {
+    if (!c) return MCULL_E_INVALID;
+    if (!c->depth.p || !c->depth_w) return fail(c, MCULL_E_STATE, "no depth buffer has been rasterised");
+    if (device_ptr) *device_ptr = (const float *)c->depth.p;
+    if (width) *width = c->depth_w;
+    if (height) *height = c->depth_h;
+    return MCULL_OK;
+}
+
+int mcull_depth_download(mcull_ctx *c, float *out) {
+    if (!c || !out) return MCULL_E_INVALID;
+    if (!c->depth.p || !c->depth_w) return fail(c, MCULL_E_STATE, "no depth buffer has been rasterised");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->depth.p, (size_t)c->depth_w * c->depth_h * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCULL_OK;
 }
 

@@ -70,6 +70,12 @@ hipError_t launch_split_meshlets(const mcull_meshlet *aos, uint64_t n, float4 *c
 hipError_t launch_bounds(const mcull_vertex *vertices, const uint32_t *meshlet_data, mcull_meshlet *meshlets,
                          uint64_t n, float4 *cone_axis_w, float4 *centre_radius, hipStream_t st);
 
+// Depth-only software rasteriser over a visible list (depth_kernels.hip); `total` is a device pointer.
+hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
+                               const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
+                               const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
+                               hipStream_t st);
+
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero)
 constexpr size_t kHizCounterBytes = 2048;
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
