@@ -19,6 +19,7 @@ Other workloads (each prints its own single JSON line):
            step (8 x (pyramid build + cull))
   hiz      the 8192^2 pyramid build alone (9.33 algorithmic bytes per pixel)
   bounds   cone/sphere computation for 64 copies of the kitten fixture's meshlets
+  depth    the depth pre-pass stand-in: visible meshlets of 4 096 kitten instances rasterised at 4K
 
 Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the kernels of the
 timed region on the stream they run on, `cpu_baseline` times the CPU oracle (a port of the
@@ -479,17 +480,69 @@ def run_bounds(env):
         env.line(out)
 
 
+# ------------------------------------------------------------------------------------------------
+# depth pre-pass stand-in: software rasterisation of the visible meshlets
+
+def run_depth(env):
+    args, mc, ctx = env.args, env.mc, env.ctx
+    w, h = args.depth_size
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kitten_scene.npz"))
+    ml, md, vt = z["meshlets"].view(mc.MESHLET), z["meshlet_data"], z["vertices"].view(mc.VERTEX)
+    n_inst = args.instances or 4096
+    t = env.host.synthetic_transforms(n_inst, extent=25.0, seed=9 + env.rank)
+    g = env.host.create_globals(eye=(40.0, 38.0, 30.0), width=w, height=h, meshlet_count=len(ml))
+    ctx.upload_meshlets(ml)
+    ctx.upload_geometry(vt, md)
+    ctx.upload_transforms(t)
+    ctx.cull(g, tests=mc.TEST_FRUSTUM | mc.TEST_CONE)
+    visible = ctx.download_count()
+    lst = ctx.download_list()
+
+    def step(k):
+        ctx.depth_rasterize(g, w, h, clear=True)
+
+    elapsed, dev_ms = env.timed(step)
+    img = ctx.depth_download()
+    covered = int((img > 0).sum())
+    tri = ml["triangleCount"].astype(np.int64)[lst["meshletID"]]
+    vc = ml["vertexCount"].astype(np.int64)[lst["meshletID"]]
+    n_tri = int(tri.sum())
+    algo = float((8 + 48 + 64 + 4 * vc + 4 * ((3 * tri + 3) // 4) + 24 * vc).sum()) + 4.0 * w * h + 4.0 * covered
+    value = n_tri * env.world / (elapsed / args.steps) / 1e9
+    if env.rank == 0:
+        out = base_line(env, "triangles depth-rasterised/sec", "G/s", value, elapsed, args.steps,
+                        "depth pre-pass stand-in: %d visible meshlets (%d triangles) of %d kitten instances into a %dx%d "
+                        "reverse-Z image, clear included" % (visible, n_tri, n_inst, w, h),
+                        {"visible_meshlets": visible, "triangles": n_tri, "covered_pixels": covered})
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "memset + depth_raster_kernel",
+                                   note="per-pixel atomic max and per-triangle set-up bound, not a streaming kernel")
+        if not args.no_cpu_baseline and env.world == 1:
+            import oracle as O
+
+            sample = min(len(lst), 20000)
+            tt = np.zeros(n_inst, dtype=O.TRANSFORM)
+            tt["model"] = t["model"]
+            sub = lst[:sample].view(O.VISIBLE)
+            reps, used = time_cpu(lambda: O.rasterize_depth(vt, md, ml, tt, sub, g, w, h), 8.0, 50)
+            tri_s = int(ml["triangleCount"].astype(np.int64)[sub["meshletID"]].sum())
+            out["cpu_baseline"] = {"value": round(tri_s * reps / used / 1e9, 5), "unit": "G/s", "cores": 1, "kind": "port",
+                                   "sample": "the first %d list entries (%d triangles) of the same frame, %d passes, one thread"
+                                             % (sample, tri_s, reps)}
+        env.line(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "hiz", "bounds"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "hiz", "bounds", "depth"])
     ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
     ap.add_argument("--meshlets-per-instance", type=int, default=0)
     ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
     ap.add_argument("--hiz", action="store_true", help="config4: also run the Hi-Z test against a 4K pyramid")
     ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
+    ap.add_argument("--depth-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"))
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
@@ -499,6 +552,8 @@ def main():
         run_hiz(env)
     elif args.workload == "bounds":
         run_bounds(env)
+    elif args.workload == "depth":
+        run_depth(env)
     else:
         run_cull(env, args.workload)
     env.close()

@@ -12,6 +12,8 @@
 //   createHiZPyramid+buildHiZPyramid :1658,:1834  Culler::buildHiZPyramid
 //   vkCmdPushConstants + vkCmdDrawMeshTasksIndirectNV :2535-2539   Culler::cull
 //   createIndirectBuffer         :1466-1506    written by Culler::cull (dynamic)
+//   depth pre-pass               :2397-2441    Culler::rasterizeDepth (software rasteriser over the visible list)
+//   loadModel..createMeshlets    :243-628      run once, then Culler::saveScene / Culler::loadScene (cache file)
 #pragma once
 
 #include <cstdint>
@@ -107,6 +109,27 @@ public:
         std::vector<DrawMeshTasksIndirectCommandNV> out(instances_);
         MCULL_CHECK(ctx_, mcull_download_commands(ctx_, out.data(), out.size() * sizeof(out[0])));
         return out;
+    }
+    // depth pre-pass stand-in over the last cull's visible list; returns the device image
+    const float *rasterizeDepth(const Globals &globals, uint32_t width, uint32_t height, bool clear = true) {
+        MCULL_CHECK(ctx_, mcull_depth_rasterize(ctx_, &globals, width, height, clear ? 1 : 0));
+        const float *ptr = nullptr;
+        MCULL_CHECK(ctx_, mcull_depth_buffer(ctx_, &ptr, nullptr, nullptr));
+        return ptr;
+    }
+    // scene cache: the arrays of Engine.hpp:215-218 written once, uploaded from the file afterwards
+    static void saveScene(const std::string &path, const std::vector<Vertex> &vertices, const std::vector<uint32_t> &indices,
+                          const std::vector<uint32_t> &meshletData, const std::vector<Meshlet> &meshlets) {
+        MCULL_CHECK(static_cast<mcull_ctx *>(nullptr),
+                    mcull_scene_save(path.c_str(), vertices.data(), vertices.size(), indices.data(), indices.size(),
+                                     meshletData.data(), meshletData.size(), meshlets.data(), meshlets.size(), nullptr,
+                                     nullptr, 0));
+    }
+    void loadScene(const std::string &path) {
+        mcull_scene_counts info{};
+        MCULL_CHECK(ctx_, mcull_scene_info(path.c_str(), &info));
+        MCULL_CHECK(ctx_, mcull_scene_upload(ctx_, path.c_str()));
+        meshletCount_ = info.meshlet_count;
     }
     void waitIdle() { MCULL_CHECK(ctx_, mcull_synchronize(ctx_)); }
     mcull_ctx *handle() const { return ctx_; }
