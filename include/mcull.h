@@ -328,6 +328,41 @@ int mcull_scene_load(const char *path, mcull_vertex *vertices, uint32_t *indices
  * (ranges are cleared when the file holds none). */
 int mcull_scene_upload(mcull_ctx *ctx, const char *path);
 
+/* ------------------------------------------------------------------ mesh pipeline */
+
+/* The reference's load-time pipeline, host code as it is there: loadModel (Engine.cpp:243-282),
+ * optimizeGeometry (Engine.cpp:338-471), createMeshlets (Engine.cpp:548-628).  A mcull_mesh owns the
+ * four arrays of Engine.hpp:215-218.  Meshlets are built with zero cone/apex/radius; mcull_mesh_upload
+ * computes those on the GPU (buildMeshletCon, Engine.cpp:472-547) and writes them back into the mesh.
+ * These calls need no context or GPU, except mcull_mesh_upload. */
+typedef struct mcull_mesh mcull_mesh;
+
+/* tinyobj::LoadObj + the dedup/quantise loop (Engine.cpp:250-281).  MCULL_E_IO when the file cannot
+ * be opened, MCULL_E_INVALID for an index outside its array. */
+int mcull_mesh_load_obj(const char *path, mcull_mesh **out);
+/* The same loop from arrays: positions xyz, optional normals xyz, optional texcoords uv, and one
+ * (position, texcoord, normal) index triple per face corner (-1 = absent), three corners per triangle. */
+int mcull_mesh_from_arrays(const float *positions, uint64_t n_positions, const float *normals, uint64_t n_normals,
+                           const float *texcoords, uint64_t n_texcoords, const int32_t *corners, uint64_t n_corners,
+                           mcull_mesh **out);
+/* optimizeGeometry: reorders the index buffer in place (same order as the reference's algorithm). */
+int mcull_mesh_optimize(mcull_mesh *mesh);
+/* createMeshlets: fills meshlets + meshletData from the current index order. */
+int mcull_mesh_build_meshlets(mcull_mesh *mesh);
+/* Sizes (range_count and checksum are zero) and read-only views of the arrays; the pointers stay
+ * valid until the next call that modifies or destroys the mesh. */
+int mcull_mesh_counts(const mcull_mesh *mesh, mcull_scene_counts *out);
+const mcull_vertex *mcull_mesh_vertices(const mcull_mesh *mesh);
+const uint32_t *mcull_mesh_indices(const mcull_mesh *mesh);
+const uint32_t *mcull_mesh_meshlet_data(const mcull_mesh *mesh);
+const mcull_meshlet *mcull_mesh_meshlets(const mcull_mesh *mesh);
+/* createMeshletBuffer + createVertexBuffer + createMeshletDataBuffer, then the GPU bounds kernel;
+ * the completed meshlet records are copied back into the mesh. */
+int mcull_mesh_upload(mcull_ctx *ctx, mcull_mesh *mesh);
+/* Writes the mesh as a scene cache file (no instance ranges). */
+int mcull_mesh_save(const mcull_mesh *mesh, const char *path);
+void mcull_mesh_destroy(mcull_mesh *mesh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,9 @@ ABI_SYMBOLS = [
     "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
     "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_enable_timing",
     "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload", "mcull_depth_rasterize", "mcull_depth_buffer", "mcull_depth_download",
+    "mcull_mesh_load_obj", "mcull_mesh_from_arrays", "mcull_mesh_optimize", "mcull_mesh_build_meshlets", "mcull_mesh_counts",
+    "mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets", "mcull_mesh_upload",
+    "mcull_mesh_save", "mcull_mesh_destroy",
 ]
 
 
@@ -121,6 +124,16 @@ _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
 _sig("mcull_depth_rasterize", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
 _sig("mcull_depth_buffer", _I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
 _sig("mcull_depth_download", _I, [_P, _P])
+_sig("mcull_mesh_load_obj", _I, [C.c_char_p, C.POINTER(_P)])
+_sig("mcull_mesh_from_arrays", _I, [_P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(_P)])
+_sig("mcull_mesh_optimize", _I, [_P])
+_sig("mcull_mesh_build_meshlets", _I, [_P])
+_sig("mcull_mesh_counts", _I, [_P, C.POINTER(SceneInfo)])
+for _name in ("mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets"):
+    _sig(_name, _P, [_P])
+_sig("mcull_mesh_upload", _I, [_P, _P])
+_sig("mcull_mesh_save", _I, [_P, C.c_char_p])
+_sig("mcull_mesh_destroy", None, [_P])
 
 
 class McullError(RuntimeError):
@@ -181,6 +194,87 @@ def load_scene(path):
                                                           ("vertices", "indices", "meshlet_data", "meshlets", "range_offset",
                                                            "range_count")]), path)
     return out
+
+
+class Mesh:
+    """The reference's load-time pipeline on the host (mcull_mesh): OBJ or arrays -> deduplicated
+    vertices -> reordered indices -> meshlets; bounds are filled in by Context.upload_mesh (GPU)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_obj(cls, path):
+        h = _P()
+        _scene_chk(lib.mcull_mesh_load_obj(str(path).encode(), C.byref(h)), path)
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, positions, corners, normals=None, texcoords=None):
+        pos = np.ascontiguousarray(positions, dtype="<f4").reshape(-1, 3)
+        cor = np.ascontiguousarray(corners, dtype="<i4").reshape(-1, 3)
+        nrm = np.zeros((0, 3), "<f4") if normals is None else np.ascontiguousarray(normals, dtype="<f4").reshape(-1, 3)
+        uv = np.zeros((0, 2), "<f4") if texcoords is None else np.ascontiguousarray(texcoords, dtype="<f4").reshape(-1, 2)
+        h = _P()
+        rc = lib.mcull_mesh_from_arrays(_np_ptr(pos), len(pos), _np_ptr(nrm), len(nrm), _np_ptr(uv), len(uv), _np_ptr(cor),
+                                        len(cor), C.byref(h))
+        if rc != OK:
+            raise McullError(rc, "mesh arrays")
+        return cls(h)
+
+    def optimize(self):
+        rc = lib.mcull_mesh_optimize(self._h)
+        if rc != OK:
+            raise McullError(rc, "optimize")
+        return self
+
+    def build_meshlets(self):
+        rc = lib.mcull_mesh_build_meshlets(self._h)
+        if rc != OK:
+            raise McullError(rc, "build_meshlets")
+        return self
+
+    def _view(self, fn, count, dtype):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        n = count * np.dtype(dtype).itemsize
+        buf = (C.c_uint8 * n).from_address(fn(self._h))
+        return np.frombuffer(bytes(buf), dtype=dtype).copy()
+
+    def counts(self):
+        info = SceneInfo()
+        lib.mcull_mesh_counts(self._h, C.byref(info))
+        return info
+
+    @property
+    def vertices(self):
+        return self._view(lib.mcull_mesh_vertices, self.counts().vertex_count, VERTEX)
+
+    @property
+    def indices(self):
+        return self._view(lib.mcull_mesh_indices, self.counts().index_count, "<u4")
+
+    @property
+    def meshlet_data(self):
+        return self._view(lib.mcull_mesh_meshlet_data, self.counts().meshlet_data_words, "<u4")
+
+    @property
+    def meshlets(self):
+        return self._view(lib.mcull_mesh_meshlets, self.counts().meshlet_count, MESHLET)
+
+    def save(self, path):
+        _scene_chk(lib.mcull_mesh_save(self._h, str(path).encode()), path)
+
+    def close(self):
+        if self._h and lib is not None:
+            lib.mcull_mesh_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class Context:
@@ -257,6 +351,10 @@ class Context:
         out = np.zeros((h, w), dtype="<f4")
         self._chk(lib.mcull_depth_download(self._h, _np_ptr(out)))
         return out
+
+    def upload_mesh(self, mesh):
+        """Upload a Mesh and complete its meshlet bounds on the GPU (written back into the mesh)."""
+        self._chk(lib.mcull_mesh_upload(self._h, mesh._h))
 
     def upload_scene(self, path):
         """Load a scene cache file and upload its meshlets, geometry and instance ranges."""
