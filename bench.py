@@ -340,20 +340,28 @@ def run_cull(env, workload):
         env.line(out)
 
 
-def pmc_traffic(args, workload, n_inst, per):
-    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE
-    doubled as the gfx950 correction prescribes, WRITE_SIZE as is; separate passes), or None when the
-    workload differs from the profiled one.  Counters cannot be collected from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_config4_summary.json")
-    if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False) or not os.path.exists(path):
+def pmc_summary_bytes(tag, kernels):
+    """HBM bytes per launch summed over `kernels` from the committed rocprofv3 PMC passes of the same
+    command (profiles/<tag>_summary.json: FETCH_SIZE doubled as the gfx950 correction prescribes,
+    WRITE_SIZE as is; separate passes).  Counters cannot be collected from inside this process."""
+    rel = os.path.join("profiles", "%s_summary.json" % tag)
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
         return None, None
     with open(path) as f:
         summ = json.load(f)
     total = 0
     for name, row in summ.items():
-        if any(k in name for k in ("cull_mask_kernel", "compact_kernel", "emit_commands_kernel")):
+        if any(k in name for k in kernels):
             total += row.get("fetch_bytes_corrected", 0) + row.get("write_bytes_corrected", 0)
-    return (total or None), "profiles/r01_bench_config4_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    return (total or None), rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+
+
+def pmc_traffic(args, workload, n_inst, per):
+    """Traffic of one step of the profiled default workload, or None when the workload differs."""
+    if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False):
+        return None, None
+    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "compact_kernel", "emit_commands_kernel"))
 
 
 def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):
@@ -410,7 +418,9 @@ def run_hiz(env):
         out = base_line(env, "Hi-Z pyramid pixels reduced/sec", "Gpixel/s", value, elapsed, args.steps,
                         "Hi-Z min pyramid of a %dx%d depth image, %d levels, one launch%s"
                         % (w, h, levels, " (replicas: every GPU builds its own)" if env.world > 1 else ""))
-        out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_tile_kernel", bytes_per_pixel=round(algo / (w * h), 3))
+        traffic, src = pmc_summary_bytes("r01_bench_hiz", ("hiz_tile_kernel",)) if (w, h) == (8192, 8192) else (None, None)
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_tile_kernel", traffic, src,
+                                   bytes_per_pixel=round(algo / (w * h), 3))
         if not args.no_cpu_baseline and env.world == 1:
             import oracle as O
 

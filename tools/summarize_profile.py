@@ -20,6 +20,19 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
+def stats_from_db(args, out_dir, summary):
+    import sqlite3
+
+    db = sqlite3.connect(sorted(glob.glob(os.path.join(args.stats, "**", "*_results.db"), recursive=True))[-1])
+    q = ("select name, count(*), avg(duration), min(duration), max(duration), sum(duration), max(vgpr_count), "
+         "max(sgpr_count), max(lds_size) from kernels where name like ? group by name order by sum(duration) desc")
+    with open(os.path.join(out_dir, "%s_kernel_stats.csv" % args.tag), "w") as o:
+        o.write("kernel,calls,avg_us,min_us,max_us,total_us,vgprs,sgprs,lds_bytes\n")
+        for name, calls, avg, mn, mx, tot, vg, sg, lds in db.execute(q, ("%" + args.prefix + "%",)):
+            o.write("%s,%d,%.3f,%.3f,%.3f,%.3f,%d,%d,%d\n" % (short(name), calls, avg / 1e3, mn / 1e3, mx / 1e3, tot / 1e3, vg, sg, lds))
+            summary.setdefault(short(name), {})["avg_us"] = round(avg / 1e3, 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -31,7 +44,9 @@ def main():
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     summary = {}
-    if args.stats:
+    if args.stats and not glob.glob(os.path.join(args.stats, "**", "*kernel_stats.csv"), recursive=True):
+        stats_from_db(args, out_dir, summary)  # rocprofv3's default output is a rocpd sqlite database
+    elif args.stats:
         f = sorted(glob.glob(os.path.join(args.stats, "**", "*kernel_stats.csv"), recursive=True))[-1]
         rows = [r for r in csv.DictReader(open(f)) if args.prefix in r["Name"]]
         with open(os.path.join(out_dir, "%s_kernel_stats.csv" % args.tag), "w") as o:
@@ -44,11 +59,19 @@ def main():
     for kind, path, factor in (("fetch", args.fetch, 2.0), ("write", args.write, 1.0)):
         if not path:
             continue
-        f = sorted(glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True))[-1]
         acc = {}
-        for r in csv.DictReader(open(f)):
-            if args.prefix in r["Kernel_Name"]:
-                acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        csvs = sorted(glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True))
+        if csvs:
+            for r in csv.DictReader(open(csvs[-1])):
+                if args.prefix in r["Kernel_Name"]:
+                    acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        else:
+            import sqlite3
+
+            db = sqlite3.connect(sorted(glob.glob(os.path.join(path, "**", "*_results.db"), recursive=True))[-1])
+            for name, value in db.execute("select kernel_name, value from counters_collection where kernel_name like ?",
+                                          ("%" + args.prefix + "%",)):
+                acc.setdefault(short(name), []).append(float(value))
         for k, v in acc.items():
             kib = sum(v) / len(v)
             summary.setdefault(k, {})["%s_size_kib_raw" % kind] = round(kib, 1)
