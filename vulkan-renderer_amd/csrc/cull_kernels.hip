@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
-    uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts) {
+    uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous) {
     constexpr uint32_t kGroups = kWaves * NG;  // groups per workgroup
     __shared__ uint4 s_rec[kGroups];
     __shared__ float4 s_x[kGroups][4];
@@ -185,7 +185,12 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     __shared__ uint32_t s_count[kWaves];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t block_g0 = blockIdx.x * kGroups;
+    // Workgroups are dealt to the 8 XCDs round-robin by id.  xcd_contiguous != 0 renumbers them so that
+    // each XCD walks one contiguous eighth of the scene (the grid is then a multiple of 8).
+    uint32_t block = blockIdx.x;
+    if (xcd_contiguous) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t block_g0 = block * kGroups;
+    if (block_g0 >= n_groups) return;  // padding workgroups of a rounded-up grid
     if (threadIdx.x < kGroups) {
         const uint32_t g = block_g0 + threadIdx.x;
         GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, v.uniform_count);
@@ -555,7 +560,7 @@ static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
     MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
                                                      s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
-                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts));
+                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u));
 }
 
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
