@@ -359,6 +359,15 @@ const mcull_meshlet *mcull_mesh_meshlets(const mcull_mesh *mesh);
 /* createMeshletBuffer + createVertexBuffer + createMeshletDataBuffer, then the GPU bounds kernel;
  * the completed meshlet records are copied back into the mesh. */
 int mcull_mesh_upload(mcull_ctx *ctx, mcull_mesh *mesh);
+/* GPU variants with identical results: the dedup loop as a parallel hash-table pass (lowest corner
+ * index per distinct vertex + a scan for the first-seen numbering), and createMeshlets as one thread
+ * per candidate start triangle + the chain of real starts; mcull_mesh_build_meshlets_gpu also uploads
+ * the mesh and completes the bounds like mcull_mesh_upload.  (The reorderer stays on the host: it is
+ * inherently sequential.) */
+int mcull_mesh_from_arrays_gpu(mcull_ctx *ctx, const float *positions, uint64_t n_positions, const float *normals,
+                               uint64_t n_normals, const float *texcoords, uint64_t n_texcoords, const int32_t *corners,
+                               uint64_t n_corners, mcull_mesh **out);
+int mcull_mesh_build_meshlets_gpu(mcull_ctx *ctx, mcull_mesh *mesh);
 /* Writes the mesh as a scene cache file (no instance ranges). */
 int mcull_mesh_save(const mcull_mesh *mesh, const char *path);
 void mcull_mesh_destroy(mcull_mesh *mesh);

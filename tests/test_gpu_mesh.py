@@ -27,3 +27,69 @@ def test_mesh_upload_completes_bounds_and_culls(mc, O, H, ctx):
     ctx.cull(g, tests=3)
     assert ctx.download_list().tobytes() == want.list.tobytes()
     assert 0 < want.total < want.n_pairs
+
+
+def _soup(seed, n_pos=300, n_tri=1500):
+    rs = np.random.RandomState(seed)
+    pos = rs.randint(-4, 5, (n_pos, 3)).astype("<f4") * 0.25
+    pos[pos == 0] *= rs.choice([1.0, -1.0], size=(pos == 0).sum())
+    if seed % 2:
+        pos[7, 1] = np.nan
+    nrm = rs.normal(size=(40, 3)).astype("<f4")
+    nrm[5] = 0.0
+    uv = rs.uniform(-2, 2, (50, 2)).astype("<f4")
+    uv[3] = [70000.0, 1e-9]
+    cor = np.empty((n_tri * 3, 3), dtype="<i4")
+    cor[:, 0] = rs.randint(0, n_pos, n_tri * 3)
+    cor[:, 1] = rs.randint(0, len(uv), n_tri * 3)
+    cor[:, 2] = rs.randint(0, len(nrm), n_tri * 3)
+    cor[30:33, 0] = cor[30, 0]
+    cor[60, 0] = cor[61, 0]
+    return pos, cor, nrm, uv
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_gpu_dedup_and_meshlets_equal_the_host_pipeline_on_soups(mc, ctx, seed):
+    """Seams, -0/+0, NaN positions, degenerate triangles, half overflow: the GPU dedup pass numbers
+    vertices exactly like the sequential loop, and the GPU meshlet builder cuts the same meshlets."""
+    pos, cor, nrm, uv = _soup(seed)
+    for kwargs in ({"normals": nrm, "texcoords": uv}, {}):
+        host = mc.Mesh.from_arrays(pos, cor, **kwargs)
+        gpu = ctx.mesh_from_arrays(pos, cor, **kwargs)
+        assert gpu.vertices.tobytes() == host.vertices.tobytes()
+        assert np.array_equal(gpu.indices, host.indices)
+        host.optimize().build_meshlets()
+        gpu.optimize()
+        ctx.build_meshlets(gpu)
+        assert np.array_equal(gpu.indices, host.indices)
+        assert np.array_equal(gpu.meshlet_data, host.meshlet_data)
+        ctx.upload_mesh(host)                      # completes the host mesh's bounds on the GPU
+        assert gpu.meshlets.tobytes() == host.meshlets.tobytes()
+        assert len(gpu.meshlets) > 10 and gpu.meshlets["radius"].any()
+
+
+def test_gpu_mesh_front_half_large(mc, O, H, ctx):
+    """The 871 200-triangle proxy: GPU dedup + host reorder + GPU meshlets + GPU bounds equals the
+    oracle's CPU pipeline in every array."""
+    pos, tris = H.proxy_mesh(660, 660, seed=12)
+    cor = np.full((tris.size, 3), -1, dtype="<i4")
+    cor[:, 0] = tris.reshape(-1)
+    mesh = ctx.mesh_from_arrays(pos, cor).optimize()
+    ctx.build_meshlets(mesh)
+    ref = O.build_mesh(pos, cor)
+    assert mesh.vertices.tobytes() == ref.vertices.tobytes()
+    assert np.array_equal(mesh.indices, ref.indices)
+    assert np.array_equal(mesh.meshlet_data, ref.meshlet_data)
+    assert mesh.meshlets.tobytes() == ref.meshlets.tobytes()
+    assert len(ref.meshlets) == 13916
+
+
+def test_gpu_mesh_errors(mc, ctx):
+    pos = np.zeros((3, 3), "<f4")
+    bad = np.array([[0, -1, -1], [1, -1, -1], [5, -1, -1]], dtype="<i4")
+    with pytest.raises(mc.McullError) as e:
+        ctx.mesh_from_arrays(pos, bad)
+    assert e.value.status == mc.E_INVALID
+    empty = ctx.mesh_from_arrays(pos, np.zeros((0, 3), "<i4"))
+    ctx.build_meshlets(empty)
+    assert len(empty.meshlets) == 0 and len(empty.vertices) == 0

@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload", "mcull_depth_rasterize", "mcull_depth_buffer", "mcull_depth_download",
     "mcull_mesh_load_obj", "mcull_mesh_from_arrays", "mcull_mesh_optimize", "mcull_mesh_build_meshlets", "mcull_mesh_counts",
     "mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets", "mcull_mesh_upload",
-    "mcull_mesh_save", "mcull_mesh_destroy",
+    "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu",
 ]
 
 
@@ -126,6 +126,8 @@ _sig("mcull_depth_buffer", _I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)
 _sig("mcull_depth_download", _I, [_P, _P])
 _sig("mcull_mesh_load_obj", _I, [C.c_char_p, C.POINTER(_P)])
 _sig("mcull_mesh_from_arrays", _I, [_P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(_P)])
+_sig("mcull_mesh_from_arrays_gpu", _I, [_P, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(_P)])
+_sig("mcull_mesh_build_meshlets_gpu", _I, [_P, _P])
 _sig("mcull_mesh_optimize", _I, [_P])
 _sig("mcull_mesh_build_meshlets", _I, [_P])
 _sig("mcull_mesh_counts", _I, [_P, C.POINTER(SceneInfo)])
@@ -351,6 +353,21 @@ class Context:
         out = np.zeros((h, w), dtype="<f4")
         self._chk(lib.mcull_depth_download(self._h, _np_ptr(out)))
         return out
+
+    def mesh_from_arrays(self, positions, corners, normals=None, texcoords=None):
+        """Mesh.from_arrays with the deduplication done on the GPU (same result)."""
+        pos = np.ascontiguousarray(positions, dtype="<f4").reshape(-1, 3)
+        cor = np.ascontiguousarray(corners, dtype="<i4").reshape(-1, 3)
+        nrm = np.zeros((0, 3), "<f4") if normals is None else np.ascontiguousarray(normals, dtype="<f4").reshape(-1, 3)
+        uv = np.zeros((0, 2), "<f4") if texcoords is None else np.ascontiguousarray(texcoords, dtype="<f4").reshape(-1, 2)
+        h = _P()
+        self._chk(lib.mcull_mesh_from_arrays_gpu(self._h, _np_ptr(pos), len(pos), _np_ptr(nrm), len(nrm), _np_ptr(uv), len(uv),
+                                                 _np_ptr(cor), len(cor), C.byref(h)))
+        return Mesh(h)
+
+    def build_meshlets(self, mesh):
+        """createMeshlets + bounds on the GPU; the mesh is left uploaded (same result as the host path)."""
+        self._chk(lib.mcull_mesh_build_meshlets_gpu(self._h, mesh._h))
 
     def upload_mesh(self, mesh):
         """Upload a Mesh and complete its meshlet bounds on the GPU (written back into the mesh)."""

@@ -180,6 +180,10 @@ uint32_t level_count(uint32_t w, uint32_t h) {
 
 }  // namespace
 
+hipStream_t mcull_ctx_stream(mcull_ctx *ctx) { return ctx->stream; }
+int mcull_ctx_device(mcull_ctx *ctx) { return ctx->device; }
+int mcull_ctx_fail(mcull_ctx *ctx, int code, const char *message) { return fail(ctx, code, "%s", message); }
+
 extern "C" {
 
 int mcull_version(void) { return MCULL_VERSION_NUMBER; }

@@ -2,6 +2,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <stdint.h>
 
 #include "../../include/mcull.h"
@@ -70,6 +72,13 @@ hipError_t launch_split_meshlets(const mcull_meshlet *aos, uint64_t n, float4 *c
 hipError_t launch_bounds(const mcull_vertex *vertices, const uint32_t *meshlet_data, mcull_meshlet *meshlets,
                          uint64_t n, float4 *cone_axis_w, float4 *centre_radius, hipStream_t st);
 
+// GPU front half of the mesh pipeline (meshlet_kernels.hip); host arrays in, host vectors out.
+hipError_t gpu_dedup_vertices(const float *pos, uint64_t npos, const float *nrm, uint64_t nnrm, const float *uv, uint64_t nuv,
+                              const int32_t *corners, uint32_t n_corners, std::vector<mcull_vertex> *vertices,
+                              std::vector<uint32_t> *indices, hipStream_t st);
+hipError_t gpu_build_meshlets(const uint32_t *indices, uint32_t n_tri, std::vector<mcull_meshlet> *meshlets,
+                              std::vector<uint32_t> *meshlet_data, hipStream_t st);
+
 // Depth-only software rasteriser over a visible list (depth_kernels.hip); `total` is a device pointer.
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
@@ -83,3 +92,8 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
 
 
 }  // namespace mcull
+
+// Accessors for the sources that work on a context without seeing its definition (mcull_capi.hip).
+hipStream_t mcull_ctx_stream(mcull_ctx *ctx);
+int mcull_ctx_device(mcull_ctx *ctx);
+int mcull_ctx_fail(mcull_ctx *ctx, int code, const char *message);

@@ -22,7 +22,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/mcull.h"
+#include "mcull_internal.h"
 
 struct mcull_mesh {
     std::vector<mcull_vertex> vertices;
@@ -414,6 +414,51 @@ int mcull_mesh_upload(mcull_ctx *ctx, mcull_mesh *mesh) {
     if (mesh->meshlets.empty()) return MCULL_OK;
     if ((rc = mcull_compute_bounds(ctx))) return rc;  // buildMeshletCon on the GPU
     return mcull_download_meshlets(ctx, mesh->meshlets.data(), mesh->meshlets.size());
+}
+
+// The same dedup loop with the per-corner work, the hash table and the first-seen numbering on the GPU.
+int mcull_mesh_from_arrays_gpu(mcull_ctx *ctx, const float *positions, uint64_t n_positions, const float *normals,
+                               uint64_t n_normals, const float *texcoords, uint64_t n_texcoords, const int32_t *corners,
+                               uint64_t n_corners, mcull_mesh **out) {
+    if (!ctx || !out) return MCULL_E_INVALID;
+    *out = nullptr;
+    if ((!positions && n_positions) || (!normals && n_normals) || (!texcoords && n_texcoords) || (!corners && n_corners) ||
+        n_corners % 3 != 0 || n_corners > 0x7ffffff0ull)
+        return mcull_ctx_fail(ctx, MCULL_E_INVALID, "mesh arrays: null pointer or corner count not a multiple of 3");
+    // index ranges are checked on the host before anything is launched (the kernels index unchecked)
+    for (uint64_t c = 0; c < n_corners; c++) {
+        const int32_t vi = corners[3 * c], ti = corners[3 * c + 1], ni = corners[3 * c + 2];
+        if (vi < 0 || (uint64_t)vi >= n_positions || (n_normals && (ni < 0 || (uint64_t)ni >= n_normals)) ||
+            (n_texcoords && (ti < 0 || (uint64_t)ti >= n_texcoords)))
+            return mcull_ctx_fail(ctx, MCULL_E_INVALID, "mesh arrays: a corner index lies outside its array");
+    }
+    mcull_mesh *m = new (std::nothrow) mcull_mesh;
+    if (!m) return MCULL_E_NOMEM;
+    if (hipSetDevice(mcull_ctx_device(ctx)) != hipSuccess) {
+        delete m;
+        return mcull_ctx_fail(ctx, MCULL_E_HIP, "hipSetDevice failed");
+    }
+    const hipError_t e = mcull::gpu_dedup_vertices(positions, n_positions, normals, n_normals, texcoords, n_texcoords, corners,
+                                                   (uint32_t)n_corners, &m->vertices, &m->indices, mcull_ctx_stream(ctx));
+    if (e != hipSuccess) {
+        delete m;
+        return mcull_ctx_fail(ctx, e == hipErrorOutOfMemory ? MCULL_E_NOMEM : MCULL_E_HIP, hipGetErrorString(e));
+    }
+    *out = m;
+    return MCULL_OK;
+}
+
+// createMeshlets on the GPU followed by mcull_mesh_upload (bounds on the GPU as well).
+int mcull_mesh_build_meshlets_gpu(mcull_ctx *ctx, mcull_mesh *mesh) {
+    if (!ctx || !mesh) return MCULL_E_INVALID;
+    if (mesh->indices.size() / 3 > 0xfffffff0ull) return mcull_ctx_fail(ctx, MCULL_E_INVALID, "too many triangles");
+    for (uint32_t i : mesh->indices)
+        if (i >= mesh->vertices.size()) return mcull_ctx_fail(ctx, MCULL_E_INVALID, "index outside the vertex array");
+    if (hipSetDevice(mcull_ctx_device(ctx)) != hipSuccess) return mcull_ctx_fail(ctx, MCULL_E_HIP, "hipSetDevice failed");
+    const hipError_t e = mcull::gpu_build_meshlets(mesh->indices.data(), (uint32_t)(mesh->indices.size() / 3), &mesh->meshlets,
+                                                   &mesh->meshlet_data, mcull_ctx_stream(ctx));
+    if (e != hipSuccess) return mcull_ctx_fail(ctx, e == hipErrorOutOfMemory ? MCULL_E_NOMEM : MCULL_E_HIP, hipGetErrorString(e));
+    return mcull_mesh_upload(ctx, mesh);
 }
 
 int mcull_mesh_save(const mcull_mesh *mesh, const char *path) {
