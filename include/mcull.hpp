@@ -13,7 +13,10 @@
 //   vkCmdPushConstants + vkCmdDrawMeshTasksIndirectNV :2535-2539   Culler::cull
 //   createIndirectBuffer         :1466-1506    written by Culler::cull (dynamic)
 //   depth pre-pass               :2397-2441    Culler::rasterizeDepth (software rasteriser over the visible list)
-//   loadModel..createMeshlets    :243-628      run once, then Culler::saveScene / Culler::loadScene (cache file)
+//   loadModel                    :243-282      Mesh::loadModel
+//   optimizeGeometry             :338-471      Mesh::optimizeGeometry
+//   createMeshlets               :548-628      Mesh::createMeshlets (host) / Culler::createMeshlets (GPU, with bounds)
+//   ... run once, then Mesh::save / Culler::loadScene (cache file)
 #pragma once
 
 #include <cstdint>
@@ -50,6 +53,34 @@ static_assert(sizeof(Vertex) == 24 && sizeof(Meshlet) == 48 && sizeof(Globals) =
                   sizeof(DrawMeshTasksIndirectCommandNV) == 8 && sizeof(DrawMeshTasksIndirectCommandEXT) == 12 && sizeof(DrawIndirect) == 28 && sizeof(Visible) == 8,
               "layout contract of shaders/common.h / Engine.hpp");
 
+// The four arrays of Engine.hpp:215-218 and the load-time pipeline that fills them.
+class Mesh {
+public:
+    Mesh() = default;
+    ~Mesh() { mcull_mesh_destroy(mesh_); }
+    Mesh(const Mesh &) = delete;
+    Mesh &operator=(const Mesh &) = delete;
+    void loadModel(const std::string &path) {
+        mcull_mesh_destroy(mesh_);
+        mesh_ = nullptr;
+        MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_mesh_load_obj(path.c_str(), &mesh_));
+    }
+    void optimizeGeometry() { MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_mesh_optimize(mesh_)); }
+    void createMeshlets() { MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_mesh_build_meshlets(mesh_)); }
+    void save(const std::string &path) const { MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_mesh_save(mesh_, path.c_str())); }
+    uint64_t meshletCount() const {
+        mcull_scene_counts n{};
+        MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_mesh_counts(mesh_, &n));
+        return n.meshlet_count;
+    }
+    const Meshlet *meshlets() const { return mcull_mesh_meshlets(mesh_); }
+    const Vertex *vertices() const { return mcull_mesh_vertices(mesh_); }
+    mcull_mesh *handle() const { return mesh_; }
+
+private:
+    mcull_mesh *mesh_ = nullptr;
+};
+
 class Culler {
 public:
     explicit Culler(int device = 0, void *hip_stream = nullptr) { MCULL_CHECK(ctx_, mcull_create(device, hip_stream, &ctx_)); }
@@ -59,6 +90,16 @@ public:
     Culler(const Culler &) = delete;
     Culler &operator=(const Culler &) = delete;
 
+    // createMeshlets on the GPU (meshlets, packed data and bounds), mesh left uploaded
+    void createMeshlets(Mesh &mesh) {
+        MCULL_CHECK(ctx_, mcull_mesh_build_meshlets_gpu(ctx_, mesh.handle()));
+        meshletCount_ = mesh.meshletCount();
+    }
+    // upload a host-built mesh and complete its bounds on the GPU
+    void uploadMesh(Mesh &mesh) {
+        MCULL_CHECK(ctx_, mcull_mesh_upload(ctx_, mesh.handle()));
+        meshletCount_ = mesh.meshletCount();
+    }
     // binding 2 (shader.task:22-24)
     void createMeshletBuffer(const std::vector<Meshlet> &meshlets) {
         meshletCount_ = meshlets.size();
