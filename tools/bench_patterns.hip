@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
         auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
         timeit("ordered: cull_mask<3,4,nt> + compact<nt> + counter reset", [&] {
             hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u);
-            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 4), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 4u);
+            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
             zero_tc();
         });
         // the scatter pass alone on the counters of one cull pass: workgroups per 256-group tile
