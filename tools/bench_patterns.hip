@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void cull_aos_kernel(const mcull_meshlet *_
     }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
+        const bool vis = pair_visible<TESTS, true>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
         const uint64_t ballot = __ballot(vis);
         if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
     }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void cull_sgpr_xform_kernel(const float4 *_
     }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const bool vis = pair_visible<TESTS>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
+        const bool vis = pair_visible<TESTS, true>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
         const uint64_t ballot = __ballot(vis);
         if (lane == 0 && gi[k].count) mask[g0 + k] = ballot;
     }

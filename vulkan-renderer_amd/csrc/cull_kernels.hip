@@ -59,7 +59,7 @@ struct Xform {
 __device__ __forceinline__ float xform_scale(float4 c0) { return sqrtf(dot3(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z)); }
 
 // shader.task:85-101 for one pair.  `a` = {axis.xyz, coneW}, `c` = {centre.xyz, radius}.
-template <uint32_t TESTS>
+template <uint32_t TESTS, bool CONE_FIRST>
 __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float scale, float4 a, float4 c) {
     // world-space centre (shader.task:91), axis (:95), radius (:99)
     const float wx = ((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x;
@@ -75,6 +75,28 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
             culled |= d < 0.0f;
         }
     }
+    // accept = !frustum && !occlusion && !cone (shader.task:101) is a conjunction, so the order of the
+    // tests cannot change it, only the cost.  The occlusion test's pyramid read is the one
+    // data-dependent memory access; the cone test is arithmetic only (two square roots, two
+    // reciprocals).  CONE_FIRST (bounds streamed from HBM, the pass is memory-bound): the cone test
+    // runs first and about half the pairs never issue the read (8 views at 8192^2: 11.1 -> 10.3 ms).
+    // Otherwise (bounds cache-resident, the pass is arithmetic-bound): the occlusion test runs first,
+    // because it empties whole waves, which then skip the cone arithmetic (1 M instances of one
+    // mesh: 68 ms against 88 ms with the cone test first).
+    auto cone_test = [&]() {
+        if ((TESTS & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
+            float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
+            float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
+            float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
+            const float ia = 1.0f / sqrtf(dot3(ax, ay, az, ax, ay, az));
+            ax *= ia; ay *= ia; az *= ia;
+            float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
+            const float iv = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+            vx *= iv; vy *= iv; vz *= iv;
+            culled = dot3(ax, ay, az, vx, vy, vz) < -a.w;
+        }
+    };
+    if (CONE_FIRST) cone_test();
     if ((TESTS & MCULL_TEST_HIZ) && !culled) {  // occlusionCull, shader.task:58-77
         const float cx = ((v.vp[0] * wx + v.vp[4] * wy) + v.vp[8] * wz) + v.vp[12];
         const float cy = ((v.vp[1] * wx + v.vp[5] * wy) + v.vp[9] * wz) + v.vp[13];
@@ -86,23 +108,14 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
         const float tv = 1.0f - (ny * 0.5f + 0.5f);
         const float px = (ndc_radius * 2.0f) * v.tex_max;
         const uint32_t mip = mip_level(px, v.levels);
-        const uint32_t lw = v.level_table[mip], lh = v.level_table[16 + mip], lo = v.level_table[32 + mip];
+        // level extents are arithmetic; only the level's offset in the flat pyramid comes from the table
+        const uint32_t lw = max(1u, v.w0 >> mip), lh = max(1u, v.h0 >> mip), lo = v.level_table[32 + mip];
         const uint32_t tx = wrap_texel(floorf(tu * (float)lw), lw);
         const uint32_t ty = wrap_texel(floorf(tv * (float)lh), lh);
         const float d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];
         culled = nz < d - 0.05f;
     }
-    if ((TESTS & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
-        float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
-        float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
-        float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
-        const float ia = 1.0f / sqrtf(dot3(ax, ay, az, ax, ay, az));
-        ax *= ia; ay *= ia; az *= ia;
-        float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
-        const float iv = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
-        vx *= iv; vy *= iv; vz *= iv;
-        culled = dot3(ax, ay, az, vx, vy, vz) < -a.w;
-    }
+    if (!CONE_FIRST) cone_test();
     return !culled;
 }
 
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
         Xform m;
         m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
         const uint32_t n_valid = s_rec[slot].z;
-        const bool vis = pair_visible<TESTS>(v, m, s_scale[slot], a[k], c[k]) && (lane < n_valid);
+        const bool vis = pair_visible<TESTS, NT>(v, m, s_scale[slot], a[k], c[k]) && (lane < n_valid);
         const uint64_t ballot = __ballot(vis);
         if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
         count += (uint32_t)__popcll(ballot);
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void cull_atomic_kernel(
             const Xform m = load_xform(transforms, gi.inst);
             if (lane < gi.count) {
                 const uint32_t id = gi.first_meshlet + lane;
-                vis = pair_visible<TESTS>(v, m, xf_scale[gi.inst], cone_axis_w[id], centre_radius[id]);
+                vis = pair_visible<TESTS, false>(v, m, xf_scale[gi.inst], cone_axis_w[id], centre_radius[id]);
             }
         }
         const uint64_t ballot = __ballot(vis);

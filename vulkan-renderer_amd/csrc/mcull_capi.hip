@@ -565,6 +565,8 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     if (p.tests & MCULL_TEST_HIZ) {
         const HizSlot &hs = c->hiz[p.hiz_view];
         v.tex_max = (float)(hs.w > hs.h ? hs.w : hs.h);
+        v.w0 = hs.w;
+        v.h0 = hs.h;
         v.levels = hs.levels;
         v.level_table = (const uint32_t *)hs.table.p;
         v.pyramid = (const float *)hs.pyramid.p;

@@ -21,6 +21,7 @@ struct ViewConst {
     float cam[3];
     float proj11;        // globals.proj[1][1]
     float tex_max;       // max(textureSize(pyramid, 0))
+    uint32_t w0, h0;     // level-0 extent; level k is max(1, w0 >> k) x max(1, h0 >> k) (Engine.cpp:1845-1846)
     uint32_t levels;
     uint32_t tests;      // MCULL_TEST_*
     uint32_t uniform_count;  // meshlets per instance when there are no per-instance ranges
