@@ -246,6 +246,55 @@ def test_errors(mc, kitten, config1):
     ctx.close()
 
 
+@pytest.mark.parametrize("compaction", [0, 1, 2])
+def test_empty_and_degenerate_scenes(mc, O, H, kitten, config1, compaction):
+    """No instances, no meshlets, one meshlet, nothing visible, everything visible, and an output
+    list that is too small (entries beyond the capacity are dropped, nothing is written past it)."""
+    import torch
+
+    g, t = config1["globals"], config1["transforms"]
+    ml = kitten["meshlets"]
+    c = mc.Context(0)
+    c.upload_meshlets(ml)
+    c.upload_transforms(t[:0])                                   # zero instances
+    c.cull(g, tests=3, compaction=compaction)
+    assert c.download_count() == 0 and len(c.download_list()) == 0
+    c.upload_transforms(t[:5])
+    g0 = g.copy(); g0["meshletCount"] = 0                        # zero meshlets per instance
+    c.cull(g0, tests=3, compaction=compaction)
+    assert c.download_count() == 0
+    assert not c.download_commands(5).view(mc.CMD)["taskCount"].any()
+    g1 = g.copy(); g1["meshletCount"] = 1                        # a single meshlet per instance
+    ref = O.cull_scene(O.View(g1), t[:5], ml, tests=0)
+    c.cull(g1, tests=0, compaction=compaction, write_mask=True)
+    assert c.download_count() == 5 == ref.total and np.array_equal(c.download_mask(), ref.mask)
+    away = H.create_globals(eye=(2.0, 2.0, 2.0), centre=(4.0, 4.0, 4.0), meshlet_count=len(ml))   # looking away
+    ref = O.cull_scene(O.View(away), t, ml, tests=1)
+    c.upload_transforms(t)
+    c.cull(away, tests=1, compaction=compaction)
+    assert c.download_count() == ref.total
+    ref_all = O.cull_scene(O.View(g), t, ml, tests=0)            # no test: every pair survives
+    c.cull(g, tests=0, compaction=compaction)
+    assert c.download_count() == ref_all.total == len(t) * len(ml)
+    if compaction == 0:
+        assert c.download_list().tobytes() == ref_all.list.tobytes()
+    # caller-owned list with a canary behind the capacity
+    cap = 1000
+    buf = torch.full((cap + 64, 2), -1, dtype=torch.int32, device="cuda")
+    c.cull(g, tests=2, compaction=compaction, list_ptr=buf.data_ptr(), list_capacity=cap)
+    total = c.download_count()
+    assert total > cap
+    assert bool((buf[cap:] == -1).all()), "entries were written past the capacity"
+    if compaction == 0:
+        ref2 = O.cull_scene(O.View(g), t, ml, tests=2)
+        want = ref2.list.view("<u4").reshape(-1, 2)[:cap]
+        assert np.array_equal(buf[:cap].cpu().numpy().view("<u4"), want)
+    with pytest.raises(mc.McullError) as e:
+        c.download_list()
+    assert e.value.status == mc.E_CAPACITY
+    c.close()
+
+
 def test_ext_command_form(mc, O, ctx, kitten, config1):
     """MCULL_CMD_EXT_GROUPS: {groupCountX = visible_i, 1, 1} records (12 bytes, or embedded at a
     caller-chosen stride/offset) plus the per-instance list offsets the EXT record has no room for."""
