@@ -244,6 +244,11 @@ def run_cull(env, workload):
     lst = torch.empty((cap, 2), device=device, dtype=torch.int32)
     cmds = [torch.zeros((n_inst, 2), device=device, dtype=torch.int32) for _ in range(2)]
     total = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(2)]
+    # multi-view: the last view writes the buffers the collectives read; the others stay context-owned
+    view_params = [[dict(tests=tests, hiz_view=v) for v in range(n_views)] for _ in range(2)]
+    for bb in range(2):
+        view_params[bb][-1].update(list_ptr=lst.data_ptr(), list_capacity=cap, commands_ptr=cmds[bb].data_ptr(),
+                                   total_ptr=total[bb].data_ptr())
     kernel_ms = []
     gathered = [None, None]
     if multi:
@@ -257,15 +262,26 @@ def run_cull(env, workload):
         if multi:
             main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
         ms = 0.0
-        for v in range(n_views):
-            if workload == "config5":  # the pyramid of every view is rebuilt from its depth each step
+        if workload == "config5" and not args.separate_views:
+            # the pyramid of every view is rebuilt from its depth each step, then ONE pass over the
+            # bounds culls all views (each into its own context-owned list / commands / count)
+            for v in range(n_views):
                 ctx.hiz_build(depth.data_ptr(), view=v, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
                 if record:
                     ms += ctx.last_kernel_ms()
-            ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
-                     list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+            ctx.cull_views(views, view_params[b])
             if record:
                 ms += ctx.last_kernel_ms()
+        else:
+            for v in range(n_views):
+                if workload == "config5":
+                    ctx.hiz_build(depth.data_ptr(), view=v, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
+                    if record:
+                        ms += ctx.last_kernel_ms()
+                ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
+                         list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+                if record:
+                    ms += ctx.last_kernel_ms()
         if multi:
             # per-rank counts -> every rank's list offset -> rebased per-instance commands, gathered
             # into one global draw-list description; runs on a side stream beside the next cull
@@ -309,7 +325,15 @@ def run_cull(env, workload):
 
     if rank == 0:
         k_ms = region_ms_per_step if world == 1 else float(np.mean(kernel_ms))
-        algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
+        if workload == "config5" and not args.separate_views:
+            # bounds and transforms are read once for all views; each view writes its own list + commands
+            vis_views = []
+            for v in range(n_views):
+                ctx.select_result(v)
+                vis_views.append(ctx.download_count())
+            algo = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in vis_views)
+        else:
+            algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
         kernels = "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)"
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / n_pairs, 4),
                      "parallelism": ("instances sharded x%d, RCCL all-gather of counts + rebased commands overlapped with the next cull" % world)
@@ -317,9 +341,12 @@ def run_cull(env, workload):
         if workload == "config5":
             w, h = hiz_size
             algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
-            kernels = "8 x (hiz_tile_kernel + cull_mask_kernel + compact_kernel + emit_commands_kernel)"
+            kernels = ("8 x hiz_tile_kernel + cull_mask_views_kernel + 8 x (compact_kernel + emit_commands_kernel)"
+                       if not args.separate_views else
+                       "8 x (hiz_tile_kernel + cull_mask_kernel + compact_kernel + emit_commands_kernel)")
             name = ("config 5: %d instances x %d unique meshlets against 8 views, one 8192^2 Hi-Z pyramid per view rebuilt "
-                    "every step, frustum+cone+hiz, ordered compaction (visible fraction is the last view's)" % (n_inst, per))
+                    "every step, frustum+cone+hiz, ordered compaction, %s (visible fraction is the last view's)"
+                    % (n_inst, per, "one pass over the bounds for all views" if not args.separate_views else "one cull per view"))
         elif workload == "config3":
             name = ("config 3: %d instances of one %d-meshlet mesh = %d meshlet-instances per GPU, frustum+cone+hiz against a "
                     "3840x2160 pyramid (unflipped projection), ordered compaction; bounds are shared, so the HBM figure "
@@ -598,6 +625,7 @@ def main():
     ap.add_argument("--hiz", action="store_true", help="config4: also run the Hi-Z test against a 4K pyramid")
     ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
     ap.add_argument("--depth-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"))
+    ap.add_argument("--separate-views", action="store_true", help="config5: one cull call per view instead of one fused pass")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")

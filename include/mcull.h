@@ -253,6 +253,17 @@ int mcull_hiz_download_level(mcull_ctx *ctx, uint32_t view, uint32_t level, floa
 int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
                mcull_cull_result *result);
 
+/* mcull_cull for up to MCULL_MAX_VIEWS views of the same scene in one pass over the meshlet bounds
+ * (the cascade / multi-camera case: the reference records one cull per render pass, Engine.cpp:2381-2551,
+ * and has no multi-view form).  globals[i] / params[i] (params may be NULL: all tests, ordered) /
+ * results[i] describe view i, which uses output slot i of the context; every view's outputs equal
+ * those of a separate mcull_cull call.  Ordered compaction only, and globals[i].meshletCount must
+ * be the same for all views.  Afterwards the download / rebase / payload / rasterise calls refer to
+ * view 0 until mcull_select_result picks another slot; mcull_cull always uses and selects slot 0. */
+int mcull_cull_views(mcull_ctx *ctx, uint32_t n_views, const mcull_globals *globals, const mcull_cull_params *params,
+                     mcull_cull_result *results);
+int mcull_select_result(mcull_ctx *ctx, uint32_t view);
+
 /* Multi-GPU: re-emits the indirect commands of the last mcull_cull with
  * firstTask += sum(totals[0..rank)), where `totals` is the device array produced by an
  * all-gather of every rank's *result.total.  No reference counterpart (single GPU). */

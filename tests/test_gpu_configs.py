@@ -193,3 +193,75 @@ def test_config5_eight_views_8k(mc, O, H, ctx):
             assert np.array_equal(cmds["taskCount"][sample], ref.commands["taskCount"])
     assert len(set(totals)) > 1 and all(0 < x < n_inst * per for x in totals)
     ctx.set_instance_ranges(None, None)
+
+
+def test_multi_view_pass_equals_separate_culls(mc, O, H, ctx, kitten):
+    """mcull_cull_views: one pass over the bounds for several views gives, per view, exactly what a
+    separate mcull_cull gives (mask, list, commands, count) - shared kitten mesh with per-view tests
+    and pyramids, and a streamed synthetic scene with per-instance ranges."""
+    ml = kitten["meshlets"]
+    n = 300
+    t = H.update_transforms(n)
+    w, h = 800, 600
+    views, params, refs = [], [], []
+    for v in range(5):
+        ang = 2 * np.pi * v / 5
+        g = H.create_globals(eye=(9 * np.cos(ang), 9 * np.sin(ang), 3.0 + v), fov_deg=40.0 + 5 * v, width=w, height=h,
+                             flip_y=bool(v & 1), meshlet_count=len(ml))
+        depth = H.synthetic_depth(w, h, n_discs=20, seed=30 + v)
+        ctx.hiz_build(depth, view=v)
+        tests = [7, 3, 5, 1, 6][v]
+        views.append(g)
+        params.append(dict(tests=tests, hiz_view=v, write_mask=True, cmd_stride=28 if v == 2 else 0, cmd_offset=20 if v == 2 else 0))
+        refs.append(O.cull_scene(O.View(g, O.hiz_build(depth), w, h), t, ml, tests=tests))
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(ml)
+    ctx.upload_transforms(t)
+    res = ctx.cull_views(views, params)
+    assert len(res) == 5
+    for v in range(5):
+        ctx.select_result(v)
+        assert ctx.download_count() == refs[v].total
+        assert np.array_equal(ctx.download_mask(), refs[v].mask)
+        assert ctx.download_list().tobytes() == refs[v].list.tobytes()
+        stride, off = (28, 20) if v == 2 else (8, 0)
+        raw = ctx.download_commands(n, stride).reshape(n, stride)
+        cmds = raw[:, off:off + 8].copy().view(mc.CMD).reshape(-1)
+        assert np.array_equal(cmds["taskCount"], refs[v].commands["taskCount"])
+        assert np.array_equal(cmds["firstTask"], refs[v].commands["firstTask"])
+    assert len({r.total for r in refs}) > 1
+    # a following single-view cull uses slot 0 again and starts from clean counters
+    ctx.cull(views[3], tests=1)
+    assert ctx.download_list().tobytes() == refs[3].list.tobytes()
+    with pytest.raises(mc.McullError):
+        ctx.cull_views(views[:2], [dict(compaction=1), dict()])          # ordered only
+    with pytest.raises(mc.McullError):
+        ctx.select_result(7)                                              # never produced
+    # streamed scene (unique meshlets, ranges), 8 views, no pyramids
+    n_inst, per = 40000, 128
+    cone, sphere = H.synthetic_bounds(n_inst * per, seed=21)
+    t2 = H.synthetic_transforms(n_inst, extent=50.0, seed=22)
+    off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+    cnt = np.full(n_inst, per, dtype="<u4")
+    ctx.upload_bounds_soa(cone, sphere)
+    ctx.upload_transforms(t2)
+    ctx.set_instance_ranges(off, cnt)
+    views = [H.create_globals(eye=(120 * np.cos(a), 120 * np.sin(a), 40.0), fov_deg=35.0, width=1920, height=1080)
+             for a in np.linspace(0, 2 * np.pi, 8, endpoint=False)]
+    ctx.cull_views(views, [dict(tests=3, write_mask=True)] * 8)
+    sample = np.sort(np.random.RandomState(3).choice(n_inst, 256, replace=False))
+    fused = []
+    for v in range(8):
+        ctx.select_result(v)
+        fused.append((ctx.download_count(), ctx.download_mask().copy(), ctx.download_list().copy(), ctx.download_commands(n_inst).copy()))
+    for v in range(8):
+        ctx.cull(views[v], tests=3, write_mask=True)
+        assert ctx.download_count() == fused[v][0]
+        assert np.array_equal(ctx.download_mask(), fused[v][1])
+        assert ctx.download_list().tobytes() == fused[v][2].tobytes()
+        assert ctx.download_commands(n_inst).tobytes() == fused[v][3].tobytes()
+        if v in (0, 5):
+            ref = O.cull_scene(O.View(views[v]), t2[sample], cone_axis_w=cone, centre_radius=sphere,
+                               ranges=(off[sample], cnt[sample]), tests=3, threads=8)
+            assert np.array_equal(fused[v][1].reshape(n_inst, per // 64)[sample].reshape(-1), ref.mask)
+    ctx.set_instance_ranges(None, None)

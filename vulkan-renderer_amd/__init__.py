@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload", "mcull_depth_rasterize", "mcull_depth_buffer", "mcull_depth_download",
     "mcull_mesh_load_obj", "mcull_mesh_from_arrays", "mcull_mesh_optimize", "mcull_mesh_build_meshlets", "mcull_mesh_counts",
     "mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets", "mcull_mesh_upload",
-    "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu",
+    "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
 ]
 
 
@@ -121,6 +121,8 @@ _sig("mcull_scene_save", _I, [C.c_char_p, _P, C.c_uint64, _P, C.c_uint64, _P, C.
 _sig("mcull_scene_info", _I, [C.c_char_p, C.POINTER(SceneInfo)])
 _sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
 _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
+_sig("mcull_cull_views", _I, [_P, _U32, _P, _P, _P])
+_sig("mcull_select_result", _I, [_P, _U32])
 _sig("mcull_depth_rasterize", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
 _sig("mcull_depth_buffer", _I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
 _sig("mcull_depth_download", _I, [_P, _P])
@@ -436,6 +438,33 @@ class Context:
         self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
         return r
+
+    def cull_views(self, globals_list, params_list=None):
+        """One pass for several views.  params_list: dicts with the keyword arguments of cull()
+        (tests, hiz_view, cmd_*, write_mask, list_ptr, list_capacity, commands_ptr, total_ptr)."""
+        n = len(globals_list)
+        g = np.zeros(n, dtype=GLOBALS)
+        for i, x in enumerate(globals_list):
+            g[i] = np.ascontiguousarray(x, dtype=GLOBALS).reshape(1)[0]
+        P = (CullParams * n)()
+        for i in range(n):
+            d = dict(tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0,
+                     write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None, total_ptr=None)
+            if params_list is not None:
+                d.update(params_list[i])
+            P[i] = CullParams(d["tests"], d["compaction"], d["hiz_view"], d["cmd_form"], d["cmd_stride"], d["cmd_offset"],
+                              int(bool(d["write_mask"])), 0, d["list_ptr"], d["list_capacity"], d["commands_ptr"], d["total_ptr"])
+        R = (CullResult * n)()
+        self._chk(lib.mcull_cull_views(self._h, n, _np_ptr(g), C.cast(P, _P), C.cast(R, _P)))
+        self._views = [(int(r.n_groups), int(r.n_pairs)) for r in R]
+        self._last = (self._views[0][0], self._views[0][1], 0)
+        return list(R)
+
+    def select_result(self, view):
+        """Point the download / rebase / payload / rasterise calls at the result of view slot `view`."""
+        self._chk(lib.mcull_select_result(self._h, view))
+        if getattr(self, "_views", None) and view < len(self._views):
+            self._last = (self._views[view][0], self._views[view][1], 0)
 
     def rebase_commands(self, device_totals_ptr, rank):
         self._chk(lib.mcull_rebase_commands(self._h, device_totals_ptr, rank))

@@ -16,6 +16,8 @@
 //                emit_commands_kernel -> {taskCount, firstTask} per instance
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
 //                workgroup step), list order unspecified.
+#include <cstring>
+
 #include "mcull_internal.h"
 
 namespace mcull {
@@ -59,8 +61,9 @@ struct Xform {
 __device__ __forceinline__ float xform_scale(float4 c0) { return sqrtf(dot3(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z)); }
 
 // shader.task:85-101 for one pair.  `a` = {axis.xyz, coneW}, `c` = {centre.xyz, radius}.
-template <uint32_t TESTS, bool CONE_FIRST>
-__device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float scale, float4 a, float4 c) {
+template <bool CONE_FIRST>
+__device__ __forceinline__ bool pair_visible_impl(const uint32_t TESTS, const ViewConst &v, const Xform &m, float scale, float4 a,
+                                                  float4 c) {
     // world-space centre (shader.task:91), axis (:95), radius (:99)
     const float wx = ((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x;
     const float wy = ((m.c0.y * c.x + m.c1.y * c.y) + m.c2.y * c.z) + m.c3.y;
@@ -117,6 +120,12 @@ __device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m,
     }
     if (!CONE_FIRST) cone_test();
     return !culled;
+}
+
+// The tests as a compile-time constant: the single-view kernels are instantiated per combination.
+template <uint32_t TESTS, bool CONE_FIRST>
+__device__ __forceinline__ bool pair_visible(const ViewConst &v, const Xform &m, float scale, float4 a, float4 c) {
+    return pair_visible_impl<CONE_FIRST>(TESTS, v, m, scale, a, c);
 }
 
 // Which instance / meshlet range a group belongs to.  All values are wave-uniform.
@@ -243,6 +252,79 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     if (threadIdx.x == 0) {
         const uint32_t sum = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
         if (sum) atomicAdd(&tile_counts[block_g0 / kTileGroups], sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same pass for several views at once: the bounds, records and transforms are read once and every
+// view's tests run on them (the 32 bytes per pair are the dominant traffic of a streamed scene, so
+// eight views cost one read instead of eight).  Each view has its own mask and tile counters; the
+// per-view constants stay in the kernel-argument segment and are fetched by scalar loads inside the
+// (wave-uniform) view loop.
+struct ViewSet {
+    ViewConst v[MCULL_MAX_VIEWS];
+    uint64_t *mask[MCULL_MAX_VIEWS];
+    uint32_t *tile_counts[MCULL_MAX_VIEWS];
+    uint32_t n;
+};
+
+template <int NG, bool NT>
+__global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
+    const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
+    const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewSet vs) {
+    constexpr uint32_t kGroups = kWaves * NG;
+    __shared__ uint4 s_rec[kGroups];
+    __shared__ float4 s_x[kGroups][4];
+    __shared__ float s_scale[kGroups];
+    __shared__ uint32_t s_count[MCULL_MAX_VIEWS][kWaves];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t block_g0 = blockIdx.x * kGroups;
+    if (threadIdx.x < kGroups) {
+        const uint32_t g = block_g0 + threadIdx.x;
+        GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, vs.v[0].uniform_count);
+        if (g >= n_groups) gi.count = 0;
+        s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
+    }
+    __syncthreads();
+    if (threadIdx.x < kGroups * 4) {
+        const uint32_t k = threadIdx.x >> 2, j = threadIdx.x & 3u;
+        s_x[k][j] = transforms[(size_t)s_rec[k].x * 4 + j];
+        if (j == 0) s_scale[k] = xf_scale[s_rec[k].x];
+    }
+    float4 a[NG], c[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const uint4 r = s_rec[wave * NG + k];
+        const uint32_t last = r.z ? r.z - 1u : 0u;
+        const uint32_t id = r.y + (lane < last ? lane : last);
+        a[k] = load_bounds<NT>(cone_axis_w + id);
+        c[k] = load_bounds<NT>(centre_radius + id);
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < vs.n; i++) {
+        const ViewConst &v = vs.v[i];
+        uint64_t *__restrict__ mask = vs.mask[i];
+        uint32_t count = 0;
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const uint32_t slot = wave * NG + k;
+            Xform m;
+            m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
+            const uint32_t n_valid = s_rec[slot].z;
+            const bool vis = pair_visible_impl<NT>(v.tests, v, m, s_scale[slot], a[k], c[k]) && (lane < n_valid);
+            const uint64_t ballot = __ballot(vis);
+            if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
+            count += (uint32_t)__popcll(ballot);
+        }
+        if (lane == 0) s_count[i][wave] = count;
+    }
+    __syncthreads();
+    if (threadIdx.x < vs.n) {
+        const uint32_t i = threadIdx.x;
+        const uint32_t sum = (s_count[i][0] + s_count[i][1]) + (s_count[i][2] + s_count[i][3]);
+        if (sum) atomicAdd(&vs.tile_counts[i][block_g0 / kTileGroups], sum);
     }
 }
 
@@ -588,6 +670,29 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
         else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, st);
         else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, st);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
+                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st) {
+    ViewSet vs;
+    std::memset(&vs, 0, sizeof vs);
+    vs.n = n_views;
+    for (uint32_t i = 0; i < n_views; i++) {
+        vs.v[i] = *views[i];
+        vs.mask[i] = masks[i];
+        vs.tile_counts[i] = tile_counts[i];
+    }
+    // two groups per wave: each group is evaluated n_views times, which hides the load latency that
+    // the single-view kernel hides with four groups in flight
+    const uint32_t per_block = kWaves * 2;
+    const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
+    if (streaming)
+        hipLaunchKernelGGL((cull_mask_views_kernel<2, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
+                           s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs);
+    else
+        hipLaunchKernelGGL((cull_mask_views_kernel<2, false>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
+                           s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs);
     return hipGetLastError();
 }
 

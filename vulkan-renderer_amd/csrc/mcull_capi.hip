@@ -55,12 +55,8 @@ struct mcull_ctx {
     uint32_t depth_w = 0, depth_h = 0;
     bool hiz_single_pass = true;
 
-    // cull scratch + outputs
-    DevBuf mask, tile_counts, super_counts, inst_first, inst_count, total, list, commands;
-    uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
-    bool counters_clean = false;  // tile/super counters are all zero (K1 adds into them, K4 re-zeroes)
-    uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
-    // description of the last cull (for rebase / downloads / payloads)
+    // cull scratch + outputs, one set per view slot: mcull_cull uses slot 0, mcull_cull_views slot i
+    // for its i-th view; `cur` is the slot the download / rebase / payload / rasterise calls refer to
     struct Last {
         bool valid = false;
         mcull::SceneDev scene{};
@@ -72,7 +68,15 @@ struct mcull_ctx {
         void *commands = nullptr;
         bool have_mask = false;
         uint64_t n_pairs = 0;
-    } last;
+    };
+    struct ViewOut {
+        DevBuf mask, tile_counts, super_counts, inst_first, inst_count, total, list, commands;
+        uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
+        bool counters_clean = false;   // tile/super counters are all zero (the mask pass adds into them, the command pass re-zeroes)
+        uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
+        Last last;                      // description of the last cull (for rebase / downloads / payloads)
+    } out[MCULL_MAX_VIEWS];
+    uint32_t cur = 0;
 };
 
 namespace {
@@ -118,6 +122,12 @@ int ensure(mcull_ctx *c, DevBuf &b, size_t bytes) {
 void release(DevBuf &b) {
     if (b.p && b.owned) (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0; b.owned = true;
+}
+
+// a changed scene makes every stored cull result meaningless
+void invalidate_results(mcull_ctx *c) {
+    for (auto &o : c->out) o.last.valid = false;
+    c->cur = 0;
 }
 
 int copy_in(mcull_ctx *c, void *dst, const void *src, size_t bytes, int mem) {
@@ -231,9 +241,11 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->mask, &c->tile_counts, &c->super_counts,
-                      &c->inst_first, &c->inst_count, &c->total, &c->list, &c->commands, &c->depth};
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth};
     for (DevBuf *b : bufs) release(*b);
+    for (auto &o : c->out)
+        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.super_counts, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
+            release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -267,7 +279,7 @@ int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t 
     c->have_aos = true;
     c->geometry_checked = false;
     c->have_bounds = true;
-    c->last.valid = false;
+    invalidate_results(c);
     return MCULL_OK;
 }
 
@@ -294,7 +306,7 @@ int mcull_upload_bounds_soa(mcull_ctx *c, const float *cone_axis_w, const float 
     c->n_meshlets = count;
     c->have_aos = false;
     c->have_bounds = true;
-    c->last.valid = false;
+    invalidate_results(c);
     return MCULL_OK;
 }
 
@@ -383,7 +395,7 @@ int mcull_upload_transforms(mcull_ctx *c, const mcull_transform *transforms, uin
     HIPCHK(c, mcull::launch_xform_scale((const float4 *)c->transforms.p, (uint32_t)count, (float *)c->xf_scale.p,
                                         c->stream));
     c->n_instances = count;
-    c->last.valid = false;
+    invalidate_results(c);
     return MCULL_OK;
 }
 
@@ -391,7 +403,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
                               uint64_t n_instances) {
     if (!c) return MCULL_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    c->last.valid = false;
+    invalidate_results(c);
     if (!meshlet_offset || !meshlet_count) {
         c->have_ranges = false;
         return MCULL_OK;
@@ -509,11 +521,29 @@ int mcull_hiz_download_level(mcull_ctx *c, uint32_t view, uint32_t level, float 
 
 // ------------------------------------------------------------------------------------ cull
 
-int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
-    if (!c) return MCULL_E_INVALID;
+namespace {
+
+// Everything mcull_cull decides before it launches: validated parameters, the scene and view
+// constants, and the output buffers of one view slot (allocated here).
+struct CullPlan {
+    mcull_cull_params p;
+    mcull::SceneDev s;
+    mcull::ViewConst v;
+    uint32_t uniform_count;
+    uint64_t n_pairs;
+    uint64_t *total;
+    mcull_visible *list;
+    uint64_t capacity;
+    void *commands;
+    mcull::CmdLayout lay;
+    bool want_mask, two_level, streaming;
+    uint32_t n_tiles;
+};
+
+int plan_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_ctx::ViewOut &o, CullPlan *plan) {
     if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
     if (!c->have_bounds) return fail(c, MCULL_E_STATE, "no meshlet bounds uploaded");
-    mcull_cull_params p;
+    mcull_cull_params &p = plan->p;
     std::memset(&p, 0, sizeof p);
     if (params) p = *params;
     else { p.tests = MCULL_TEST_ALL; p.compaction = MCULL_COMPACT_ORDERED; }
@@ -526,16 +556,15 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+%u <= stride", record);
     if ((p.tests & MCULL_TEST_HIZ) && (p.hiz_view >= MCULL_MAX_VIEWS || !c->hiz[p.hiz_view].built))
         return fail(c, MCULL_E_STATE, "Hi-Z test requested but no pyramid built for view %u", p.hiz_view);
-    HIPCHK(c, hipSetDevice(c->device));
 
-    mcull::SceneDev s{};
+    mcull::SceneDev &s = plan->s;
+    s = mcull::SceneDev{};
     s.cone_axis_w = (const float4 *)c->cone.p;
     s.centre_radius = (const float4 *)c->sphere.p;
     s.transforms = (const float4 *)c->transforms.p;
     s.xf_scale = (const float *)c->xf_scale.p;
     s.n_instances = (uint32_t)c->n_instances;
-    uint64_t n_pairs;
-    uint32_t uniform_count = 0;
+    plan->uniform_count = 0;
     if (c->have_ranges) {
         if (c->ranged_instances != c->n_instances)
             return fail(c, MCULL_E_STATE, "instance ranges cover %llu instances, transforms %llu",
@@ -545,23 +574,24 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
         s.group_rec = (const uint4 *)c->group_rec.p;
         s.groups_per_instance = 0;
         s.n_groups = c->ranged_groups;
-        n_pairs = c->ranged_pairs;
+        plan->n_pairs = c->ranged_pairs;
     } else {
-        uniform_count = g->meshletCount;  // shader.task:85
-        if (uniform_count > c->n_meshlets) return fail(c, MCULL_E_INVALID, "globals.meshletCount exceeds uploaded meshlets");
-        s.groups_per_instance = (uniform_count + 63u) / 64u;
+        plan->uniform_count = g->meshletCount;  // shader.task:85
+        if (plan->uniform_count > c->n_meshlets) return fail(c, MCULL_E_INVALID, "globals.meshletCount exceeds uploaded meshlets");
+        s.groups_per_instance = (plan->uniform_count + 63u) / 64u;
         s.n_groups = (uint64_t)s.groups_per_instance * c->n_instances;
-        n_pairs = (uint64_t)uniform_count * c->n_instances;
+        plan->n_pairs = (uint64_t)plan->uniform_count * c->n_instances;
         if (s.n_groups >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "more than 2^32 meshlet groups");
     }
 
-    mcull::ViewConst v{};
+    mcull::ViewConst &v = plan->v;
+    v = mcull::ViewConst{};
     std::memcpy(v.frustum, g->frustum, sizeof v.frustum);
     mat4_mul(g->proj, g->view, v.vp);
     camera_position(g->view, v.cam);
     v.proj11 = g->proj[5];
     v.tests = p.tests;
-    v.uniform_count = uniform_count;
+    v.uniform_count = plan->uniform_count;
     if (p.tests & MCULL_TEST_HIZ) {
         const HizSlot &hs = c->hiz[p.hiz_view];
         v.tex_max = (float)(hs.w > hs.h ? hs.w : hs.h);
@@ -573,152 +603,236 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     }
 
     int rc;
-    const bool want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
-    if (want_mask && (rc = ensure(c, c->mask, s.n_groups * 8))) return rc;
-    if ((rc = ensure(c, c->total, 256))) return rc;
-    uint64_t *total = p.total ? p.total : (uint64_t *)c->total.p;
-    mcull_visible *list = p.list;
-    uint64_t capacity = p.list_capacity;
-    if (!list) {
-        if (capacity == 0) capacity = n_pairs;
-        if ((rc = ensure(c, c->list, capacity * sizeof(mcull_visible)))) return rc;
-        list = (mcull_visible *)c->list.p;
+    plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
+    if (plan->want_mask && (rc = ensure(c, o.mask, s.n_groups * 8))) return rc;
+    if ((rc = ensure(c, o.total, 256))) return rc;
+    plan->total = p.total ? p.total : (uint64_t *)o.total.p;
+    plan->list = p.list;
+    plan->capacity = p.list_capacity;
+    if (!plan->list) {
+        if (plan->capacity == 0) plan->capacity = plan->n_pairs;
+        if ((rc = ensure(c, o.list, plan->capacity * sizeof(mcull_visible)))) return rc;
+        plan->list = (mcull_visible *)o.list.p;
     }
-    void *commands = p.commands;
-    if (!commands) {
+    plan->commands = p.commands;
+    if (!plan->commands) {
         const size_t bytes = (size_t)c->n_instances * p.cmd_stride;
-        // bytes of a record outside the 8-byte command are never written by the kernels: the
+        // bytes of a record outside the command itself are never written by the kernels: the
         // context-owned buffer is zeroed whenever it is (re)allocated or its record layout changes
         const uint64_t layout_key = ((uint64_t)p.cmd_stride << 32) | ((uint64_t)p.cmd_form << 24) | p.cmd_offset;
-        const bool fresh = !c->commands.p || c->commands.cap < bytes || c->commands_layout != layout_key;
-        if ((rc = ensure(c, c->commands, bytes))) return rc;
-        if (fresh) HIPCHK(c, hipMemsetAsync(c->commands.p, 0, c->commands.cap, c->stream));
-        c->commands_layout = layout_key;
-        commands = c->commands.p;
+        const bool fresh = !o.commands.p || o.commands.cap < bytes || o.commands_layout != layout_key;
+        if ((rc = ensure(c, o.commands, bytes))) return rc;
+        if (fresh) HIPCHK(c, hipMemsetAsync(o.commands.p, 0, o.commands.cap, c->stream));
+        o.commands_layout = layout_key;
+        plan->commands = o.commands.p;
     }
-    const uint32_t n_tiles = mcull::tile_count_for(s.n_groups);
-    const mcull::CmdLayout lay{p.cmd_stride, p.cmd_offset, p.cmd_form};
-
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (s.n_groups == 0) {
-        HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
-        if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
-        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands, nullptr, c->stream));
-    } else if (p.compaction == MCULL_COMPACT_ORDERED) {
-        const bool two_level = mcull::needs_super_counts(s.n_groups);
-        if (!c->tile_counts.p || c->tile_counts.cap < (size_t)n_tiles * 4) c->counters_clean = false;
-        if ((rc = ensure(c, c->tile_counts, (size_t)n_tiles * 4))) return rc;
-        if (two_level && (rc = ensure(c, c->super_counts, (size_t)mcull::super_count_for(s.n_groups) * 4))) return rc;
-        if ((rc = ensure(c, c->inst_first, (c->n_instances + 1) * 4))) return rc;
-        if (!c->counters_clean) HIPCHK(c, hipMemsetAsync(c->tile_counts.p, 0, c->tile_counts.cap, c->stream));
-        c->counters_clean = false;  // until the command kernel that re-zeroes them has been enqueued
-        // bounds that cannot stay cache-resident between culls are read with the streaming hint
-        const bool streaming = c->n_meshlets * 32ull > (64ull << 20);
-        HIPCHK(c, mcull::launch_cull_mask(s, v, (uint64_t *)c->mask.p, (uint32_t *)c->tile_counts.p, streaming,
-                                          c->stream));
-        HIPCHK(c, mcull::launch_compact(s, (const uint64_t *)c->mask.p, (const uint32_t *)c->tile_counts.p,
-                                        two_level ? (uint32_t *)c->super_counts.p : nullptr, list, capacity,
-                                        (uint32_t *)c->inst_first.p, total, n_pairs * 8ull > (64ull << 20), c->stream));
-        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, (const uint32_t *)c->inst_first.p, nullptr,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands,
-                                              (uint32_t *)c->tile_counts.p, c->stream));
-        c->counters_clean = true;
+    plan->n_tiles = mcull::tile_count_for(s.n_groups);
+    plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
+    plan->two_level = mcull::needs_super_counts(s.n_groups);
+    // bounds that cannot stay cache-resident between culls are read with the streaming hint
+    plan->streaming = c->n_meshlets * 32ull > (64ull << 20);
+    if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
+        if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
-        if ((rc = ensure(c, c->inst_count, (c->n_instances + 1) * 4))) return rc;
-        HIPCHK(c, hipMemsetAsync(total, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
-        HIPCHK(c, mcull::launch_cull_atomic(s, v, list, capacity, (uint32_t *)c->inst_count.p, total,
-                                            p.write_mask ? (uint64_t *)c->mask.p : nullptr,
-                                            p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
-        HIPCHK(c, mcull::launch_emit_commands(s, uniform_count, nullptr, (const uint32_t *)c->inst_count.p,
-                                              (const uint64_t *)total, nullptr, 0, lay, commands, nullptr, c->stream));
+        if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
+        if ((rc = ensure(c, o.tile_counts, (size_t)plan->n_tiles * 4))) return rc;
+        if (plan->two_level && (rc = ensure(c, o.super_counts, (size_t)mcull::super_count_for(s.n_groups) * 4))) return rc;
+        if ((rc = ensure(c, o.inst_first, (c->n_instances + 1) * 4))) return rc;
+        if (!o.counters_clean) HIPCHK(c, hipMemsetAsync(o.tile_counts.p, 0, o.tile_counts.cap, c->stream));
+        o.counters_clean = false;  // until the command kernel that re-zeroes them has been enqueued
+    }
+    return MCULL_OK;
+}
+
+// scatter + commands of the ordered path (after the mask pass has filled mask and tile counters)
+int launch_ordered_tail(mcull_ctx *c, mcull_ctx::ViewOut &o, const CullPlan &pl) {
+    HIPCHK(c, mcull::launch_compact(pl.s, (const uint64_t *)o.mask.p, (const uint32_t *)o.tile_counts.p,
+                                    pl.two_level ? (uint32_t *)o.super_counts.p : nullptr, pl.list, pl.capacity,
+                                    (uint32_t *)o.inst_first.p, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
+    HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, (const uint32_t *)o.inst_first.p, nullptr,
+                                          (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands,
+                                          (uint32_t *)o.tile_counts.p, c->stream));
+    o.counters_clean = true;
+    return MCULL_OK;
+}
+
+void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *result) {
+    o.last.valid = true;
+    o.total_ptr = pl.total;
+    o.last.scene = pl.s;
+    o.last.uniform_count = pl.uniform_count;
+    o.last.compaction = pl.p.compaction;
+    o.last.lay = pl.lay;
+    o.last.list = pl.list;
+    o.last.capacity = pl.capacity;
+    o.last.commands = pl.commands;
+    o.last.have_mask = pl.want_mask && pl.s.n_groups > 0;
+    o.last.n_pairs = pl.n_pairs;
+    if (result) {
+        result->list = pl.list;
+        result->commands = pl.commands;
+        result->total = (const uint64_t *)pl.total;
+        result->mask = o.last.have_mask ? (const uint64_t *)o.mask.p : nullptr;
+        result->n_groups = pl.s.n_groups;
+        result->n_pairs = pl.n_pairs;
+        result->first_task =
+            (pl.p.compaction == MCULL_COMPACT_ORDERED && pl.s.n_groups > 0) ? (const uint32_t *)o.inst_first.p : nullptr;
+    }
+}
+
+}  // namespace
+
+int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
+    if (!c) return MCULL_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    mcull_ctx::ViewOut &o = c->out[0];
+    CullPlan pl;
+    if (int rc = plan_cull(c, g, params, o, &pl)) return rc;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (pl.s.n_groups == 0) {
+        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
+                                              (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
+    } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
+        HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
+                                          c->stream));
+        if (int rc = launch_ordered_tail(c, o, pl)) return rc;
+    } else {
+        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_cull_atomic(pl.s, pl.v, pl.list, pl.capacity, (uint32_t *)o.inst_count.p, pl.total,
+                                            pl.p.write_mask ? (uint64_t *)o.mask.p : nullptr,
+                                            pl.p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
+                                              (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     }
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;
     }
+    finish_cull(o, pl, result);
+    c->cur = 0;
+    return MCULL_OK;
+}
 
-    c->last.valid = true;
-    c->total_ptr = total;
-    c->last.scene = s;
-    c->last.uniform_count = uniform_count;
-    c->last.compaction = p.compaction;
-    c->last.lay = lay;
-    c->last.list = list;
-    c->last.capacity = capacity;
-    c->last.commands = commands;
-    c->last.have_mask = want_mask && s.n_groups > 0;
-    c->last.n_pairs = n_pairs;
-    if (result) {
-        result->list = list;
-        result->commands = commands;
-        result->total = (const uint64_t *)total;
-        result->mask = c->last.have_mask ? (const uint64_t *)c->mask.p : nullptr;
-        result->n_groups = s.n_groups;
-        result->n_pairs = n_pairs;
-        result->first_task = (p.compaction == MCULL_COMPACT_ORDERED && s.n_groups > 0) ? (const uint32_t *)c->inst_first.p : nullptr;
+int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, const mcull_cull_params *params,
+                     mcull_cull_result *results) {
+    if (!c) return MCULL_E_INVALID;
+    if (n_views == 0 || n_views > MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "n_views must be 1..%d", MCULL_MAX_VIEWS);
+    if (!globals) return fail(c, MCULL_E_INVALID, "globals is null");
+    HIPCHK(c, hipSetDevice(c->device));
+    CullPlan pl[MCULL_MAX_VIEWS];
+    for (uint32_t i = 0; i < n_views; i++) {
+        if (int rc = plan_cull(c, &globals[i], params ? &params[i] : nullptr, c->out[i], &pl[i])) return rc;
+        if (pl[i].p.compaction != MCULL_COMPACT_ORDERED)
+            return fail(c, MCULL_E_INVALID, "mcull_cull_views supports ordered compaction only (view %u)", i);
+        if (pl[i].uniform_count != pl[0].uniform_count)
+            return fail(c, MCULL_E_INVALID, "view %u: globals.meshletCount differs from view 0", i);
     }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (pl[0].s.n_groups == 0) {
+        for (uint32_t i = 0; i < n_views; i++) {
+            mcull_ctx::ViewOut &o = c->out[i];
+            HIPCHK(c, hipMemsetAsync(pl[i].total, 0, 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+            HIPCHK(c, mcull::launch_emit_commands(pl[i].s, pl[i].uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
+                                                  (const uint64_t *)pl[i].total, nullptr, 0, pl[i].lay, pl[i].commands, nullptr,
+                                                  c->stream));
+        }
+    } else {
+        // one pass over the bounds for every view, then each view's scatter + commands
+        const mcull::ViewConst *vc[MCULL_MAX_VIEWS];
+        uint64_t *masks[MCULL_MAX_VIEWS];
+        uint32_t *counts[MCULL_MAX_VIEWS];
+        for (uint32_t i = 0; i < n_views; i++) {
+            vc[i] = &pl[i].v;
+            masks[i] = (uint64_t *)c->out[i].mask.p;
+            counts[i] = (uint32_t *)c->out[i].tile_counts.p;
+        }
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream));
+        for (uint32_t i = 0; i < n_views; i++)
+            if (int rc = launch_ordered_tail(c, c->out[i], pl[i])) return rc;
+    }
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
+    for (uint32_t i = 0; i < n_views; i++) finish_cull(c->out[i], pl[i], results ? &results[i] : nullptr);
+    c->cur = 0;
+    return MCULL_OK;
+}
+
+int mcull_select_result(mcull_ctx *c, uint32_t view) {
+    if (!c) return MCULL_E_INVALID;
+    if (view >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view %u out of range", view);
+    if (!c->out[view].last.valid) return fail(c, MCULL_E_STATE, "view slot %u holds no cull result", view);
+    c->cur = view;
     return MCULL_OK;
 }
 
 int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t rank) {
     if (!c) return MCULL_E_INVALID;
-    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result to rebase");
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result to rebase");
     if (!device_totals && rank) return fail(c, MCULL_E_INVALID, "device_totals is null");
-    if (c->last.lay.form == MCULL_CMD_EXT_GROUPS)
+    if (o.last.lay.form == MCULL_CMD_EXT_GROUPS)
         return fail(c, MCULL_E_INVALID, "EXT records carry no firstTask to rebase; offset first_task on the consumer side");
     HIPCHK(c, hipSetDevice(c->device));
-    const bool ordered = c->last.compaction == MCULL_COMPACT_ORDERED && c->last.scene.n_groups > 0;
-    HIPCHK(c, mcull::launch_emit_commands(c->last.scene, c->last.uniform_count,
-                                          ordered ? (const uint32_t *)c->inst_first.p : nullptr,
-                                          ordered ? nullptr : (const uint32_t *)c->inst_count.p,
-                                          (const uint64_t *)c->total_ptr, device_totals, rank, c->last.lay,
-                                          c->last.commands, nullptr, c->stream));
+    const bool ordered = o.last.compaction == MCULL_COMPACT_ORDERED && o.last.scene.n_groups > 0;
+    HIPCHK(c, mcull::launch_emit_commands(o.last.scene, o.last.uniform_count,
+                                          ordered ? (const uint32_t *)o.inst_first.p : nullptr,
+                                          ordered ? nullptr : (const uint32_t *)o.inst_count.p,
+                                          (const uint64_t *)o.total_ptr, device_totals, rank, o.last.lay,
+                                          o.last.commands, nullptr, c->stream));
     return MCULL_OK;
 }
 
 uint64_t mcull_task_payload_count(const mcull_ctx *c) {
-    if (!c || !c->last.valid || c->last.scene.ranges) return 0;
-    return (uint64_t)((c->last.uniform_count + 31u) / 32u) * c->last.scene.n_instances;
+    if (!c) return 0;
+    const mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid || o.last.scene.ranges) return 0;
+    return (uint64_t)((o.last.uniform_count + 31u) / 32u) * o.last.scene.n_instances;
 }
 
 int mcull_emit_task_payloads(mcull_ctx *c, mcull_task_payload *out) {
     if (!c || !out) return MCULL_E_INVALID;
-    if (!c->last.valid || !c->last.have_mask) return fail(c, MCULL_E_STATE, "no cull result with a visibility mask");
-    if (c->last.scene.ranges) return fail(c, MCULL_E_INVALID, "task payloads need a uniform meshlet count");
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid || !o.last.have_mask) return fail(c, MCULL_E_STATE, "no cull result with a visibility mask");
+    if (o.last.scene.ranges) return fail(c, MCULL_E_INVALID, "task payloads need a uniform meshlet count");
     HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t ppi = (c->last.uniform_count + 31u) / 32u;
-    HIPCHK(c, mcull::launch_task_payloads(c->last.scene, (const uint64_t *)c->mask.p, out,
-                                          (uint64_t)ppi * c->last.scene.n_instances, ppi, c->stream));
+    const uint32_t ppi = (o.last.uniform_count + 31u) / 32u;
+    HIPCHK(c, mcull::launch_task_payloads(o.last.scene, (const uint64_t *)o.mask.p, out,
+                                          (uint64_t)ppi * o.last.scene.n_instances, ppi, c->stream));
     return MCULL_OK;
 }
 
 int mcull_download_count(mcull_ctx *c, uint64_t *total) {
     if (!c || !total) return MCULL_E_INVALID;
-    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(total, c->total_ptr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(total, o.total_ptr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCULL_OK;
 }
 
 int mcull_download_list(mcull_ctx *c, mcull_visible *out, uint64_t capacity, uint64_t *total) {
     if (!c) return MCULL_E_INVALID;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
     uint64_t n = 0;
     int rc = mcull_download_count(c, &n);
     if (rc) return rc;
     if (total) *total = n;
-    if (n > c->last.capacity)
+    if (n > o.last.capacity)
         return fail(c, MCULL_E_CAPACITY, "visible list needs %llu entries, device capacity is %llu",
-                    (unsigned long long)n, (unsigned long long)c->last.capacity);
+                    (unsigned long long)n, (unsigned long long)o.last.capacity);
     if (n > capacity)
         return fail(c, MCULL_E_CAPACITY, "visible list needs %llu entries, host capacity is %llu",
                     (unsigned long long)n, (unsigned long long)capacity);
     if (n && !out) return fail(c, MCULL_E_INVALID, "out is null");
     if (n) {
-        HIPCHK(c, hipMemcpyAsync(out, c->last.list, n * sizeof(mcull_visible), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out, o.last.list, n * sizeof(mcull_visible), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return MCULL_OK;
@@ -726,12 +840,13 @@ int mcull_download_list(mcull_ctx *c, mcull_visible *out, uint64_t capacity, uin
 
 int mcull_download_commands(mcull_ctx *c, void *out, uint64_t bytes) {
     if (!c || !out) return MCULL_E_INVALID;
-    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result");
-    const uint64_t have = (uint64_t)c->last.scene.n_instances * c->last.lay.stride;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    const uint64_t have = (uint64_t)o.last.scene.n_instances * o.last.lay.stride;
     if (bytes > have) return fail(c, MCULL_E_INVALID, "requested %llu bytes of %llu", (unsigned long long)bytes, (unsigned long long)have);
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes) {
-        HIPCHK(c, hipMemcpyAsync(out, c->last.commands, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out, o.last.commands, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return MCULL_OK;
@@ -739,11 +854,12 @@ int mcull_download_commands(mcull_ctx *c, void *out, uint64_t bytes) {
 
 int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
     if (!c || !out) return MCULL_E_INVALID;
-    if (!c->last.valid || !c->last.have_mask) return fail(c, MCULL_E_STATE, "no visibility mask kept");
-    if (words > c->last.scene.n_groups) return fail(c, MCULL_E_INVALID, "requested more words than groups");
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid || !o.last.have_mask) return fail(c, MCULL_E_STATE, "no visibility mask kept");
+    if (words > o.last.scene.n_groups) return fail(c, MCULL_E_INVALID, "requested more words than groups");
     HIPCHK(c, hipSetDevice(c->device));
     if (words) {
-        HIPCHK(c, hipMemcpyAsync(out, c->mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out, o.mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return MCULL_OK;
@@ -753,13 +869,14 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
 
 int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, uint32_t height, int clear) {
     if (!c) return MCULL_E_INVALID;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
     if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
     if (width == 0 || height == 0 || width > 16384 || height > 16384) return fail(c, MCULL_E_INVALID, "depth size %ux%u", width, height);
-    if (!c->last.valid) return fail(c, MCULL_E_STATE, "no cull result to rasterise");
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result to rasterise");
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_geometry(c)) return rc;
     // the list's meshlet ids index the AoS records: they must be the array the cull ran on
-    if (c->last.scene.cone_axis_w != (const float4 *)c->cone.p)
+    if (o.last.scene.cone_axis_w != (const float4 *)c->cone.p)
         return fail(c, MCULL_E_STATE, "the last cull ran on adopted SoA bounds, not on the uploaded meshlets");
     const size_t bytes = (size_t)width * height * 4;
     const bool resized = c->depth_w != width || c->depth_h != height;
@@ -770,7 +887,7 @@ int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, 
     float vp[16];
     mat4_mul(g->proj, g->view, vp);
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, mcull::launch_depth_raster(c->last.list, (const uint64_t *)c->total_ptr, c->last.capacity,
+    HIPCHK(c, mcull::launch_depth_raster(o.last.list, (const uint64_t *)o.total_ptr, o.last.capacity,
                                          (const mcull_meshlet *)c->aos.p, (const uint32_t *)c->mdata.p,
                                          (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, vp, width,
                                          height, (float *)c->depth.p, c->stream));
