@@ -135,6 +135,14 @@ public:
         MCULL_CHECK(ctx_, mcull_cull(ctx_, &globals, params, &r));
         return r;
     }
+    // several views of the same scene in one pass over the bounds; view i uses output slot i
+    std::vector<mcull_cull_result> cullViews(const std::vector<Globals> &globals, const std::vector<mcull_cull_params> &params = {}) {
+        std::vector<mcull_cull_result> r(globals.size());
+        MCULL_CHECK(ctx_, mcull_cull_views(ctx_, static_cast<uint32_t>(globals.size()), globals.data(),
+                                           params.empty() ? nullptr : params.data(), r.data()));
+        return r;
+    }
+    void selectResult(uint32_t view) { MCULL_CHECK(ctx_, mcull_select_result(ctx_, view)); }
     uint64_t visibleCount() {
         uint64_t n = 0;
         MCULL_CHECK(ctx_, mcull_download_count(ctx_, &n));
