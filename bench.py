@@ -118,6 +118,18 @@ class Env:
         max over ranks; device milliseconds between HIP events on the kernels' stream)."""
         steps = self.args.steps if steps is None else steps
         warmup = self.args.warmup if warmup is None else warmup
+        if self.args.ramp_ms > 0:
+            # After the idle set-up phase the GPU needs ~30 ms of continuous load before its clocks reach
+            # their sustained state (measured: 0.66 ms per step over the first 20 steps, 0.60 ms from
+            # about step 40 on).  Run the step untimed for ramp_ms before the W warm-up steps, so that
+            # K timed steps measure sustained throughput whatever W and K are.
+            t_ramp = time.perf_counter()
+            k = 0
+            while (time.perf_counter() - t_ramp) * 1e3 < self.args.ramp_ms:
+                for _ in range(8):
+                    step(k)
+                    k += 1
+                torch.cuda.synchronize()
         for k in range(warmup):
             step(k)
         self.fence()
@@ -154,7 +166,7 @@ def base_line(env, metric, unit, value, elapsed, steps, workload, extra_config=N
     return {
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": env.world, "steps": steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "config": cfg,
+        "dtype": "f32", "data": "synthetic", "config": cfg, "ramp_ms": a.ramp_ms,
     }
 
 
@@ -208,7 +220,8 @@ def run_cull(env, workload):
         cone, sphere, xf = make_scene(device, n_inst, per, seed=42 + rank)
         off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
         cnt = np.full(n_inst, per, dtype="<u4")
-        ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE, adopt=True)
+        ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE,
+                              adopt=not args.copy_bounds)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         ctx.set_instance_ranges(off, cnt)
         g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
@@ -278,8 +291,11 @@ def run_cull(env, workload):
                     ctx.hiz_build(depth.data_ptr(), view=v, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
                     if record:
                         ms += ctx.last_kernel_ms()
-                ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
-                         list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+                if args.ctx_outputs:
+                    ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, total_ptr=total[b].data_ptr())
+                else:
+                    ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
+                             list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
                 if record:
                     ms += ctx.last_kernel_ms()
         if multi:
@@ -616,8 +632,8 @@ def run_meshbuild(env):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "hiz", "bounds", "depth", "meshbuild"])
     ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
     ap.add_argument("--meshlets-per-instance", type=int, default=0)
@@ -626,6 +642,10 @@ def main():
     ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
     ap.add_argument("--depth-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"))
     ap.add_argument("--separate-views", action="store_true", help="config5: one cull call per view instead of one fused pass")
+    ap.add_argument("--ctx-outputs", action="store_true", help="experiment: context-owned list/commands instead of torch tensors")
+    ap.add_argument("--copy-bounds", action="store_true", help="experiment: copy the bounds into library-owned memory instead of adopting")
+    ap.add_argument("--ramp-ms", type=float, default=60.0,
+                    help="milliseconds of untimed load before the warm-up steps (clock ramp after the idle set-up); 0 = off")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")

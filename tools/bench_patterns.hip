@@ -233,6 +233,21 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
             zero_tc();
         });
+        {   // the same three launches, 20 steps back to back without a host synchronisation in between
+            auto one = [&] {
+                hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u);
+                hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
+                zero_tc();
+            };
+            for (int rep = 0; rep < 3; rep++) {
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 20; i++) one();
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("ordered, 20 steps back to back: %.1f us per step\n", ms * 50);
+            }
+        }
         // the scatter pass alone on the counters of one cull pass: workgroups per 256-group tile
         hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u);
         timeit("compact<nt> alone, 1 workgroup per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u); });
