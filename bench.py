@@ -101,9 +101,12 @@ class Env:
         self.mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
         self.host = importlib.import_module("vulkan-renderer_amd.host")
         self.mdist = importlib.import_module("vulkan-renderer_amd.dist")
-        self.ctx = self.mc.Context(self.local_rank)
-        # HIP events on the stream the kernels are launched on (the context's stream = the null
-        # stream), bracketing exactly the timed region
+        # The library runs on a stream of its own, not on the null stream: work on the null stream waits for
+        # everything enqueued earlier on the other streams of the process, which would serialise each
+        # cull behind the previous step's collective instead of overlapping them.
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx = self.mc.Context(self.local_rank, stream=self.stream.cuda_stream)
+        # HIP events on the stream the kernels are launched on, bracketing exactly the timed region
         self.hip = ctypes.CDLL("libamdhip64.so.7")
         self.ev0, self.ev1 = ctypes.c_void_p(), ctypes.c_void_p()
         assert self.hip.hipEventCreate(ctypes.byref(self.ev0)) == 0 and self.hip.hipEventCreate(ctypes.byref(self.ev1)) == 0
@@ -118,6 +121,7 @@ class Env:
         max over ranks; device milliseconds between HIP events on the kernels' stream)."""
         steps = self.args.steps if steps is None else steps
         warmup = self.args.warmup if warmup is None else warmup
+        torch.cuda.synchronize()  # tensors prepared on torch's stream are complete before the library's stream reads them
         if self.args.ramp_ms > 0:
             # After the idle set-up phase the GPU needs ~30 ms of continuous load before its clocks reach
             # their sustained state (measured: 0.66 ms per step over the first 20 steps, 0.60 ms from
@@ -134,10 +138,10 @@ class Env:
             step(k)
         self.fence()
         t0 = time.perf_counter()
-        assert self.hip.hipEventRecord(self.ev0, None) == 0
+        assert self.hip.hipEventRecord(self.ev0, ctypes.c_void_p(self.stream.cuda_stream)) == 0
         for k in range(steps):
             step(k)
-        assert self.hip.hipEventRecord(self.ev1, None) == 0
+        assert self.hip.hipEventRecord(self.ev1, ctypes.c_void_p(self.stream.cuda_stream)) == 0
         self.fence()
         elapsed = time.perf_counter() - t0
         dev_ms = ctypes.c_float()
@@ -209,6 +213,7 @@ def run_cull(env, workload):
         c_np, s_np = env.host.synthetic_bounds(per, seed=5)  # one shared mesh
         cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
         xf = make_transforms(device, n_inst, 70.0, gen)
+        torch.cuda.synchronize()
         ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=per, mem=mc.MEM_DEVICE, adopt=True)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         off = cnt = None
@@ -218,6 +223,7 @@ def run_cull(env, workload):
     else:
         n_inst, per = (args.instances or 781250), (args.meshlets_per_instance or 128)
         cone, sphere, xf = make_scene(device, n_inst, per, seed=42 + rank)
+        torch.cuda.synchronize()
         off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
         cnt = np.full(n_inst, per, dtype="<u4")
         ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE,
@@ -248,6 +254,7 @@ def run_cull(env, workload):
                                                      fov_deg=30.0 + 5 * v, width=w, height=h, flip_y=bool(v & 1)))
         else:
             depth = torch.from_numpy(env.host.synthetic_depth(w, h, 64, 1234)).to(device)
+        torch.cuda.synchronize()
         for v in range(n_views):
             ctx.hiz_build(depth.data_ptr(), view=v, width=w, height=h, mem=mc.MEM_DEVICE)
 
@@ -255,8 +262,11 @@ def run_cull(env, workload):
     # buffered so that the gather of step k overlaps the cull of step k+1
     cap = n_pairs if workload != "config3" else (1 << 30)
     lst = torch.empty((cap, 2), device=device, dtype=torch.int32)
-    cmds = [torch.zeros((n_inst, 2), device=device, dtype=torch.int32) for _ in range(2)]
-    total = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(2)]
+    # one extra row per command buffer: the visible count (uint64) is written there, so that one
+    # all-gather per step carries both the commands and the counts
+    cmds_packed = [torch.zeros((n_inst + 1, 2), device=device, dtype=torch.int32) for _ in range(2)]
+    cmds = [x[:n_inst] for x in cmds_packed]
+    total = [x[n_inst:].view(torch.int64) for x in cmds_packed]
     # multi-view: the last view writes the buffers the collectives read; the others stay context-owned
     view_params = [[dict(tests=tests, hiz_view=v) for v in range(n_views)] for _ in range(2)]
     for bb in range(2):
@@ -268,7 +278,7 @@ def run_cull(env, workload):
         comm = torch.cuda.Stream(device=device)
         ev_cull = [torch.cuda.Event() for _ in range(2)]
         ev_comm = [torch.cuda.Event() for _ in range(2)]
-        main = torch.cuda.current_stream(device)
+        main = env.stream
 
     def step(k, record=False, gather_lists=False):
         b = k & 1
@@ -305,10 +315,7 @@ def run_cull(env, workload):
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_cull[b])
 
-                def rebase(totals_all, rk, cb=cmds[b]):
-                    cb[:, 1] += totals_all[:rk].sum().to(torch.int32)
-
-                gathered[b] = env.mdist.gather_draw_list(total[b], cmds[b], rebase)
+                gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b])
                 if gather_lists:
                     env.mdist.gather_visible_lists(lst, gathered[b][0])
                 ev_comm[b].record(comm)
@@ -327,8 +334,8 @@ def run_cull(env, workload):
     with_lists = None
     if multi:  # the gathered description must be consistent on every rank
         totals_all, cmds_all = gathered[0]
-        assert totals_all.numel() == world and cmds_all.shape[0] == world * n_inst
-        mine = cmds_all[rank * n_inst:(rank + 1) * n_inst].to(torch.int64)
+        assert totals_all.numel() == world and tuple(cmds_all.shape) == (world, n_inst, 2)
+        mine = cmds_all[rank].to(torch.int64)
         assert int(mine[:, 0].sum()) == int(totals_all[rank]) and int(mine[0, 1]) == int(totals_all[:rank].sum())
         if args.gather_lists:
             # the same step including the optional all-gather of the visible lists themselves
@@ -352,7 +359,7 @@ def run_cull(env, workload):
             algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
         kernels = "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)"
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / n_pairs, 4),
-                     "parallelism": ("instances sharded x%d, RCCL all-gather of counts + rebased commands overlapped with the next cull" % world)
+                     "parallelism": ("instances sharded x%d, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % world)
                      if multi else "single GPU"}
         if workload == "config5":
             w, h = hiz_size
@@ -450,6 +457,7 @@ def run_hiz(env):
     w, h = args.hiz_size
     gen = torch.Generator(device=device).manual_seed(11 + env.rank)
     depth = torch.rand((h, w), device=device, dtype=torch.float32, generator=gen)
+    torch.cuda.synchronize()
 
     def step(k):
         ctx.hiz_build(depth.data_ptr(), view=0, width=w, height=h, mem=mc.MEM_DEVICE)

@@ -143,6 +143,12 @@ def _rank_main(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "cmds_%d.npy" % rank), cmds_all.numpy())
     np.save(os.path.join(out_dir, "totals_%d.npy" % rank), totals_all.numpy())
     np.save(os.path.join(out_dir, "list_%d.npy" % rank), r.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4"))
+    # the one-collective form: commands + count row gathered at once, rebased after the gather
+    packed = torch.zeros((len(r.commands) + 1, 2), dtype=torch.int32)
+    packed[:-1] = torch.from_numpy(r.commands.view("<i4").reshape(-1, 2).copy())
+    packed[-1] = torch.from_numpy(np.array([r.total], dtype="<u8").view("<i4").copy())
+    totals_p, cmds_p = D.gather_draw_list_packed(packed)
+    assert torch.equal(totals_p, totals_all) and torch.equal(cmds_p.reshape(-1, 2), cmds_all)
     # optional third step: the packed global list (drawIDs made global before the gather)
     cap = len(ml) * (n_inst // world + 1)
     lst = torch.zeros((cap, 2), dtype=torch.int32)
