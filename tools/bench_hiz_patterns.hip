@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void per_level_kernel(const float *__restrict__
 
 int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const uint32_t sizes[][2] = {{800, 600}, {3840, 2160}, {8192, 8192}};
+    const uint32_t sizes[][2] = {{800, 600}, {1280, 720}, {1920, 1080}, {2560, 1440}, {3840, 2160}, {4096, 4096}, {7680, 4320}, {8192, 8192}};
     for (auto &sz : sizes) {
         const uint32_t w = sz[0], h = sz[1];
         uint32_t levels = 1; for (uint32_t m = std::max(w, h); m > 1; m >>= 1) levels++;
