@@ -183,6 +183,24 @@ def test_hiz_rebuild_same_buffer_sees_no_stale_texels(mc, O, ctx, shape):
                 assert x.view("<u4").tobytes() == y.view("<u4").tobytes(), "level %d differs" % k
 
 
+def test_hiz_single_launch_form(mc, O, monkeypatch):
+    """MCULL_HIZ_SINGLE_LAUNCH=1: levels >= 7 finished inside the tile launch by the last-arriving
+    waves (tickets, write-through hand-over).  Same pyramids bit for bit, also when rebuilt into the
+    same buffer with different depth."""
+    monkeypatch.setenv("MCULL_HIZ_SINGLE_LAUNCH", "1")
+    c = mc.Context(0)
+    monkeypatch.delenv("MCULL_HIZ_SINGLE_LAUNCH")
+    rs = np.random.RandomState(17)
+    for h, w in ((600, 800), (65, 127), (1080, 1920), (2160, 3840), (37, 4000), (1, 300), (4096, 4096), (130, 129)):
+        a = rs.uniform(0, 1, (h, w)).astype("<f4")
+        for depth in (a, (1.0 - a).astype("<f4")):
+            ref = O.hiz_levels(O.hiz_build(depth, threads=8), w, h)
+            c.hiz_build(depth, view=1)
+            for k, (x, y) in enumerate(zip(c.hiz_download(view=1), ref)):
+                assert x.view("<u4").tobytes() == y.view("<u4").tobytes(), "%dx%d level %d" % (w, h, k)
+    c.close()
+
+
 def test_hiz_large_closed_form(mc, ctx):
     """8192^2 (config 5's size): level k equals the block minimum of level 0 (size-independent property)."""
     import torch

@@ -1,4 +1,5 @@
-// Single-launch Hi-Z min-depth pyramid for gfx950.
+// Hi-Z min-depth pyramid for gfx950: levels 0-6 in one pass over the depth image, the rest by a
+// second one-workgroup launch (default) or inside the same launch (single_pass).
 //
 // Reference: shaders/shader.comp:12-31 run once per level with a barrier in between
 // (Engine.cpp:1834-1866): level 0 copies the depth image, level k takes the 2x2 minimum of

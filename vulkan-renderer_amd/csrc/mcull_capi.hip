@@ -53,7 +53,7 @@ struct mcull_ctx {
     DevBuf depth_staging, hiz_counter;
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
     uint32_t depth_w = 0, depth_h = 0;
-    bool hiz_single_pass = true;
+    bool hiz_single_pass = false;  // levels >= 7 finished inside the tile launch instead of by a second small launch
 
     // cull scratch + outputs, one set per view slot: mcull_cull uses slot 0, mcull_cull_views slot i
     // for its i-th view; `cur` is the slot the download / rebase / payload / rasterise calls refer to
@@ -230,8 +230,12 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
         return MCULL_E_HIP;
     }
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const char *two_pass = std::getenv("MCULL_HIZ_TWO_PASS");
-    c->hiz_single_pass = !(two_pass && two_pass[0] == '1');
+    // Both forms read the depth image once and build levels 0-6 of each 64x64 tile in one workgroup.
+    // Finishing levels >= 7 with a second one-workgroup launch measured faster than or equal to the
+    // in-launch hand-over at every size from 800x600 to 8192^2, so it is the default; the single-launch
+    // form stays selectable for callers that want one dispatch.
+    const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
+    c->hiz_single_pass = single && single[0] == '1';
     *out = c;
     return MCULL_OK;
 }
