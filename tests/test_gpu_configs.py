@@ -265,3 +265,60 @@ def test_multi_view_pass_equals_separate_culls(mc, O, H, ctx, kitten):
                                ranges=(off[sample], cnt[sample]), tests=3, threads=8)
             assert np.array_equal(fused[v][1].reshape(n_inst, per // 64)[sample].reshape(-1), ref.mask)
     ctx.set_instance_ranges(None, None)
+
+
+def test_config4_full_size(mc, O, H):
+    """The headline workload at its full size: 781 250 instances x 128 unique meshlets = 100 M
+    meshlet-instances generated on the device, frustum + cone, ordered compaction.  Size-independent
+    properties of the whole output plus 512 sampled instances compared with the oracle bit for bit."""
+    import importlib
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    dev = torch.device("cuda", 0)
+    n_inst, per = 781250, 128
+    cone, sphere, xf = bench.make_scene(dev, n_inst, per, seed=42)
+    torch.cuda.synchronize()
+    off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+    cnt = np.full(n_inst, per, dtype="<u4")
+    c = mc.Context(0)
+    c.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE, adopt=True)
+    c.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
+    c.set_instance_ranges(off, cnt)
+    g = H.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
+    lst = torch.empty((n_inst * per, 2), device=dev, dtype=torch.int32)
+    cmds = torch.zeros((n_inst, 2), device=dev, dtype=torch.int32)
+    r = c.cull(g, tests=3, list_ptr=lst.data_ptr(), list_capacity=n_inst * per, commands_ptr=cmds.data_ptr(), write_mask=True)
+    total = c.download_count()
+    assert r.n_pairs == 100_000_000 and 0.3 < total / r.n_pairs < 0.7
+    cm = cmds.to(torch.int64)
+    assert int(cm[:, 0].sum()) == total
+    assert torch.equal(cm[:, 1], torch.cumsum(cm[:, 0], 0) - cm[:, 0])
+    keys = (lst[:total, 0].to(torch.int64) << 32) | lst[:total, 1].to(torch.int64)
+    assert bool((keys[1:] > keys[:-1]).all())
+    del keys
+    assert torch.equal(torch.bincount(lst[:total, 0].to(torch.int64), minlength=n_inst), cm[:, 0])
+    inst = lst[:total, 0].to(torch.int64)
+    assert bool(((lst[:total, 1].to(torch.int64) - inst * per) < per).all()) and bool((lst[:total, 1].to(torch.int64) >= inst * per).all())
+    del inst
+    sample = np.sort(np.random.RandomState(8).choice(n_inst, 512, replace=False))
+    idx = torch.from_numpy((sample[:, None].astype(np.int64) * per + np.arange(per)[None, :]).reshape(-1)).to(dev)
+    cs, ss = cone[idx].cpu().numpy(), sphere[idx].cpu().numpy()
+    ts = np.zeros(len(sample), dtype=O.TRANSFORM)
+    ts["model"] = xf[torch.from_numpy(sample).to(dev)].cpu().numpy()
+    ref = O.cull_scene(O.View(g), ts, cone_axis_w=cs, centre_radius=ss,
+                       ranges=((np.arange(len(sample)) * per).astype("<u4"), np.full(len(sample), per, "<u4")), tests=3, threads=8)
+    mask = c.download_mask().reshape(n_inst, per // 64)
+    assert np.array_equal(mask[sample].reshape(-1), ref.mask)
+    assert np.array_equal(cm[:, 0].cpu().numpy()[sample], ref.commands["taskCount"])
+    first = cm[:, 1].cpu().numpy()
+    pos = 0
+    for k, i in enumerate(sample):
+        n = int(ref.commands["taskCount"][k])
+        got = lst[int(first[i]): int(first[i]) + n].cpu().numpy().astype("<u4")
+        want = ref.list[pos: pos + n]
+        assert (got[:, 0] == i).all() and np.array_equal(got[:, 1] - i * per, want["meshletID"] - k * per)
+        pos += n
+    c.close()
