@@ -13,6 +13,7 @@ all-gathered over RCCL into one global draw list description (firstTask rebased 
 counts on the device, no host round trip).
 
 Other workloads (each prints its own single JSON line):
+  config1  the reference's own scene (1000 kitten instances, 800x600) as a two-phase frame
   config3  1 M instances of one 13 916-meshlet mesh (13.9 G meshlet-instances) with Hi-Z against a
            3840x2160 pyramid; shared bounds, so the bound is the per-pair arithmetic and the list
   config5  the default scene culled against 8 views, each with its own 8192^2 pyramid rebuilt in the
@@ -543,6 +544,82 @@ def run_bounds(env):
 
 
 # ------------------------------------------------------------------------------------------------
+# config 1: the reference's own scene as a two-phase frame
+
+def run_config1(env):
+    """1000 kitten instances at 800x600 (Engine.cpp:2353-2379 transforms, :2323-2352 camera): phase-1
+    cull (frustum + cone), depth pre-pass stand-in over the survivors, Hi-Z pyramid, phase-2 cull with
+    all three tests - the frame of Engine.cpp:2381-2551 without the raster hardware."""
+    args, mc, ctx = env.args, env.mc, env.ctx
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kitten_scene.npz"))
+    ml, md, vt = z["meshlets"].view(mc.MESHLET), z["meshlet_data"], z["vertices"].view(mc.VERTEX)
+    n_inst, w, h = 1000, 800, 600
+    t = env.host.update_transforms(n_inst)
+    g = env.host.create_globals(width=w, height=h, meshlet_count=len(ml))
+    ctx.upload_meshlets(ml)
+    ctx.upload_geometry(vt, md)
+    ctx.upload_transforms(t)
+    ms_parts = []
+
+    def step(k, record=False):
+        parts = []
+        ctx.cull(g, tests=mc.TEST_FRUSTUM | mc.TEST_CONE)
+        if record: parts.append(ctx.last_kernel_ms())
+        ctx.depth_rasterize(g, w, h, clear=True)
+        if record: parts.append(ctx.last_kernel_ms())
+        ptr, _, _ = ctx.depth_buffer()
+        ctx.hiz_build(ptr, view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+        if record: parts.append(ctx.last_kernel_ms())
+        ctx.cull(g, tests=mc.TEST_ALL, hiz_view=0)
+        if record:
+            parts.append(ctx.last_kernel_ms())
+            ms_parts.append(parts)
+
+    elapsed, dev_ms = env.timed(step)
+    ctx.enable_timing(True)
+    for k in range(10):
+        step(k, record=True)
+    ctx.enable_timing(False)
+    env.fence()
+    visible2 = ctx.download_count()
+    n_pairs = n_inst * len(ml)
+    parts = np.mean(np.array(ms_parts), axis=0)
+    value = 2 * n_pairs * env.world / (elapsed / args.steps) / 1e9
+    if env.rank == 0:
+        out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", value, elapsed, args.steps,
+                        "config 1: the reference scene, %d kitten instances x %d meshlets at %dx%d as a two-phase frame "
+                        "(cull frustum+cone -> depth pre-pass stand-in -> Hi-Z pyramid -> cull with all tests); both culls counted"
+                        % (n_inst, len(ml), w, h),
+                        {"meshlet_instances_per_frame": 2 * n_pairs, "visible_after_phase2": visible2,
+                         "ms_cull1_raster_hiz_cull2": [round(float(x), 4) for x in parts]})
+        algo = 2 * (32.0 * len(ml) + 72.0 * n_inst) + 8.0 * visible2 + 9.33 * w * h
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "cull_mask + compact + emit, depth_raster, hiz_tile + hiz_generic, cull_mask + compact + emit",
+                                   note="launch- and latency-bound at this size (11 launches per frame)")
+        if not args.no_cpu_baseline and env.world == 1:
+            import oracle as O
+
+            tt = np.zeros(n_inst, dtype=O.TRANSFORM)
+            tt["model"] = t["model"]
+
+            def frame(threads):
+                r1 = O.cull_scene(O.View(g), tt, ml, tests=3, threads=threads)
+                img = O.rasterize_depth(vt, md, ml, tt, r1.list, g, w, h)
+                pyr = O.hiz_build(img, threads=threads)
+                return O.cull_scene(O.View(g, pyr, w, h), tt, ml, tests=7, threads=threads)
+
+            threads = host_threads()
+            ref = frame(threads)
+            assert ref.total == visible2, "GPU frame and oracle frame disagree"
+            reps, used = time_cpu(lambda: frame(threads), 8.0, 200)
+            reps1, used1 = time_cpu(lambda: frame(1), 6.0, 50)
+            out["cpu_baseline"] = {"value": round(2 * n_pairs * reps / used / 1e9, 4), "unit": "G/s", "cores": threads, "kind": "port",
+                                   "value_1_thread": round(2 * n_pairs * reps1 / used1 / 1e9, 4),
+                                   "sample": "the same frame (culls on %d threads, rasteriser on one), %d frames; one thread: %d frames"
+                                             % (threads, reps, reps1)}
+        env.line(out)
+
+
+# ------------------------------------------------------------------------------------------------
 # depth pre-pass stand-in: software rasterisation of the visible meshlets
 
 def run_depth(env):
@@ -642,7 +719,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="config4", choices=["config4", "config3", "config5", "hiz", "bounds", "depth", "meshbuild"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config1", "config3", "config5", "hiz", "bounds", "depth", "meshbuild"])
     ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
     ap.add_argument("--meshlets-per-instance", type=int, default=0)
     ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
@@ -663,6 +740,8 @@ def main():
         run_hiz(env)
     elif args.workload == "bounds":
         run_bounds(env)
+    elif args.workload == "config1":
+        run_config1(env)
     elif args.workload == "depth":
         run_depth(env)
     elif args.workload == "meshbuild":
