@@ -576,12 +576,25 @@ def run_config1(env):
             ms_parts.append(parts)
 
     elapsed, dev_ms = env.timed(step)
+    graph_ms = None
+    if args.graph:
+        # The frame allocates nothing and never synchronises after its first run, so the caller can
+        # capture its 11 launches into one HIP graph on the library's stream and replay it per frame.
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=env.stream):
+            step(0)
+        el_g, dev_g = env.timed(lambda k: graph.replay())
+        graph_ms = dev_g / args.steps
+        graph_visible = ctx.download_count()
+        graph_depth = ctx.depth_download()
     ctx.enable_timing(True)
     for k in range(10):
         step(k, record=True)
     ctx.enable_timing(False)
     env.fence()
     visible2 = ctx.download_count()
+    if graph_ms is not None:  # the replayed frames must have produced the same frame
+        assert graph_visible == visible2 and np.array_equal(graph_depth, ctx.depth_download())
     n_pairs = n_inst * len(ml)
     parts = np.mean(np.array(ms_parts), axis=0)
     value = 2 * n_pairs * env.world / (elapsed / args.steps) / 1e9
@@ -591,7 +604,8 @@ def run_config1(env):
                         "(cull frustum+cone -> depth pre-pass stand-in -> Hi-Z pyramid -> cull with all tests); both culls counted"
                         % (n_inst, len(ml), w, h),
                         {"meshlet_instances_per_frame": 2 * n_pairs, "visible_after_phase2": visible2,
-                         "ms_cull1_raster_hiz_cull2": [round(float(x), 4) for x in parts]})
+                         "ms_cull1_raster_hiz_cull2": [round(float(x), 4) for x in parts],
+                         "ms_per_frame_replayed_as_hip_graph": None if graph_ms is None else round(graph_ms, 4)})
         algo = 2 * (32.0 * len(ml) + 72.0 * n_inst) + 8.0 * visible2 + 9.33 * w * h
         out["roofline"] = roofline(algo, dev_ms / args.steps, "cull_mask + compact + emit, depth_raster, hiz_tile + hiz_generic, cull_mask + compact + emit",
                                    note="launch- and latency-bound at this size (11 launches per frame)")
@@ -731,6 +745,7 @@ def main():
     ap.add_argument("--copy-bounds", action="store_true", help="experiment: copy the bounds into library-owned memory instead of adopting")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
                     help="milliseconds of untimed load before the warm-up steps (clock ramp after the idle set-up); 0 = off")
+    ap.add_argument("--graph", action="store_true", help="config1: also replay the frame as one captured HIP graph")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
