@@ -138,3 +138,46 @@ def test_depth_errors(mc, H, kitten, config1):
     c.depth_rasterize(g, 64, 64)
     assert c.depth_download().shape == (64, 64)
     c.close()
+
+
+def test_frame_can_be_captured_as_a_hip_graph(mc, O, kitten, config1):
+    """After one ordinary run the two-phase frame allocates nothing and never synchronises, so it can
+    be captured on the context's stream and replayed; the replay reproduces the frame (also after the
+    transforms in the captured buffer have been overwritten in place)."""
+    import torch
+
+    g, t = config1["globals"], config1["transforms"][:300]
+    ml = kitten["meshlets"]
+    w, h = 640, 480
+    stream = torch.cuda.Stream()
+    c = mc.Context(0, stream=stream.cuda_stream)
+    c.upload_meshlets(ml)
+    c.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+    xf = torch.from_numpy(t["model"].copy()).cuda()
+    torch.cuda.synchronize()
+    c.upload_transforms(xf.data_ptr(), count=len(t), mem=mc.MEM_DEVICE)
+
+    def frame():
+        c.cull(g, tests=3)
+        c.depth_rasterize(g, w, h)
+        ptr, _, _ = c.depth_buffer()
+        c.hiz_build(ptr, view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+        c.cull(g, tests=7, hiz_view=0)
+
+    frame()
+    c.synchronize()
+    want_total, want_list, want_depth = c.download_count(), c.download_list().copy(), c.depth_download().copy()
+    ref1 = O.cull_scene(O.View(g), t, ml, tests=3)
+    img = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, ref1.list, g, w, h)
+    ref2 = O.cull_scene(O.View(g, O.hiz_build(img), w, h), t, ml, tests=7)
+    assert want_total == ref2.total and want_list.tobytes() == ref2.list.tobytes()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        frame()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert c.download_count() == want_total
+    assert c.download_list().tobytes() == want_list.tobytes()
+    assert np.array_equal(c.depth_download().view("<u4"), want_depth.view("<u4"))
+    c.close()
