@@ -105,22 +105,41 @@ static void m4_inverse(const float *m, float *out) {
  * depth test GREATER_OR_EQUAL on a buffer cleared to 0 (Engine.cpp:975, :2404).  Sub-pixel
  * snapping and the exact interpolation of a hardware rasteriser are implementation-defined; the
  * canonical software form used here: float edge functions at pixel centres, top-left fill rule,
- * screen-space barycentric depth, fragments outside 0 <= z <= 1 dropped, triangles with a vertex
- * at or behind the eye plane (w <= 0) dropped instead of clipped.  Every expression fixes its
- * association order. */
+ * screen-space barycentric depth, fragments outside 0 <= z <= 1 dropped.  Triangles are clipped in
+ * clip space against the near plane z <= w (Sutherland-Hodgman, the intersection at
+ * t = d_p / (d_p - d_q) with d = w - z, each coordinate p + t*(q - p)); what remains has w > 0 for a
+ * projection whose near plane lies in front of the eye, anything else is dropped.  Every expression
+ * fixes its association order. */
 typedef struct { float x, y, z; int ok; } screen_vert;
+typedef struct { float x, y, z, w; } clip_vert;
 
-static screen_vert project_vertex(const float *mvp, const float *pos, float wf, float hf) {
+static clip_vert clip_vertex(const float *mvp, const float *pos) {
+    clip_vert r;
+    r.x = ((M(mvp, 0, 0) * pos[0] + M(mvp, 0, 1) * pos[1]) + M(mvp, 0, 2) * pos[2]) + M(mvp, 0, 3);
+    r.y = ((M(mvp, 1, 0) * pos[0] + M(mvp, 1, 1) * pos[1]) + M(mvp, 1, 2) * pos[2]) + M(mvp, 1, 3);
+    r.z = ((M(mvp, 2, 0) * pos[0] + M(mvp, 2, 1) * pos[1]) + M(mvp, 2, 2) * pos[2]) + M(mvp, 2, 3);
+    r.w = ((M(mvp, 3, 0) * pos[0] + M(mvp, 3, 1) * pos[1]) + M(mvp, 3, 2) * pos[2]) + M(mvp, 3, 3);
+    return r;
+}
+
+static screen_vert to_screen(clip_vert c, float wf, float hf) {
     screen_vert r;
-    float cx = ((M(mvp, 0, 0) * pos[0] + M(mvp, 0, 1) * pos[1]) + M(mvp, 0, 2) * pos[2]) + M(mvp, 0, 3);
-    float cy = ((M(mvp, 1, 0) * pos[0] + M(mvp, 1, 1) * pos[1]) + M(mvp, 1, 2) * pos[2]) + M(mvp, 1, 3);
-    float cz = ((M(mvp, 2, 0) * pos[0] + M(mvp, 2, 1) * pos[1]) + M(mvp, 2, 2) * pos[2]) + M(mvp, 2, 3);
-    float cw = ((M(mvp, 3, 0) * pos[0] + M(mvp, 3, 1) * pos[1]) + M(mvp, 3, 2) * pos[2]) + M(mvp, 3, 3);
-    r.ok = cw > 0.0f;
-    float nx = cx / cw, ny = cy / cw;
-    r.z = cz / cw;
+    r.ok = c.w > 0.0f;
+    float nx = c.x / c.w, ny = c.y / c.w;
+    r.z = c.z / c.w;
     r.x = (nx * 0.5f + 0.5f) * wf;   /* viewport transform, Engine.cpp:2413-2420 */
     r.y = (ny * 0.5f + 0.5f) * hf;
+    return r;
+}
+
+static clip_vert clip_intersect(clip_vert p, clip_vert q) {
+    float dp = p.w - p.z, dq = q.w - q.z;
+    float t = dp / (dp - dq);
+    clip_vert r;
+    r.x = p.x + t * (q.x - p.x);
+    r.y = p.y + t * (q.y - p.y);
+    r.z = p.z + t * (q.z - p.z);
+    r.w = p.w + t * (q.w - p.w);
     return r;
 }
 
@@ -171,10 +190,28 @@ void orc_rasterize_depth(const mcull_vertex *vertices, const uint32_t *meshlet_d
         m4_mul(vp, transforms[list[e].drawID].model, mvp);
         const uint32_t *globals = meshlet_data + m->dataOffset;
         const uint8_t *locals = (const uint8_t *)(globals + m->vertexCount);
-        screen_vert sv[64];
-        for (uint32_t i = 0; i < m->vertexCount; i++) sv[i] = project_vertex(mvp, &vertices[globals[i]].vx, (float)w, (float)h);
-        for (uint32_t t = 0; t < m->triangleCount; t++)
-            raster_triangle(sv[locals[3 * t]], sv[locals[3 * t + 1]], sv[locals[3 * t + 2]], w, h, depth);
+        clip_vert cv[64];
+        for (uint32_t i = 0; i < m->vertexCount; i++) cv[i] = clip_vertex(mvp, &vertices[globals[i]].vx);
+        for (uint32_t t = 0; t < m->triangleCount; t++) {
+            clip_vert tri[3] = {cv[locals[3 * t]], cv[locals[3 * t + 1]], cv[locals[3 * t + 2]]};
+            int in[3], n_in = 0;
+            for (int k = 0; k < 3; k++) { in[k] = (tri[k].w - tri[k].z) >= 0.0f; n_in += in[k]; }
+            if (n_in == 0) continue;
+            clip_vert poly[4]; int np = 0;
+            if (n_in == 3) {
+                poly[0] = tri[0]; poly[1] = tri[1]; poly[2] = tri[2]; np = 3;
+            } else {
+                for (int k = 0; k < 3; k++) {           /* edges 0->1, 1->2, 2->0 in winding order */
+                    int q = (k + 1) % 3;
+                    if (in[k]) poly[np++] = tri[k];
+                    if (in[k] != in[q]) poly[np++] = in[k] ? clip_intersect(tri[k], tri[q]) : clip_intersect(tri[q], tri[k]);
+                }
+            }
+            screen_vert sv[4];
+            for (int k = 0; k < np; k++) sv[k] = to_screen(poly[k], (float)w, (float)h);
+            raster_triangle(sv[0], sv[1], sv[2], w, h, depth);
+            if (np == 4) raster_triangle(sv[0], sv[2], sv[3], w, h, depth);
+        }
     }
 }
 

@@ -129,3 +129,33 @@ def test_kitten_scene_renders_plausibly(O, H, kitten, config1):
     full = np.array([(i, m) for i in range(len(t)) for m in range(len(kitten["meshlets"]))], dtype=O.VISIBLE)
     img_full = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], kitten["meshlets"], t, full, g, 800, 600)
     assert np.array_equal(img, img_full)
+
+
+def test_near_plane_clipping(O):
+    """A triangle with one vertex behind the near plane is clipped in clip space (the visible part is
+    a trapezoid), not dropped.  The model matrix makes clip.w = pos.z and clip.z = 0.25, so a vertex is
+    inside the near plane iff pos.z >= 0.25; with these dyadic coordinates the intersections fall at
+    t = 0.5 exactly and the expected image can be evaluated independently."""
+    w = h = 16
+    model = np.zeros((4, 4), dtype="<f4")        # [c][r]
+    model[0, 0] = 1.0; model[1, 1] = 1.0         # x, y pass through
+    model[3, 2] = 0.25                           # clip.z = 0.25 (constant)
+    model[2, 3] = 1.0                            # clip.w = pos.z
+    A, B, C = (-0.5, -0.5, 1.0), (0.5, -0.5, 1.0), (0.0, 1.0, -0.5)
+    front = np.array([A, C, B], dtype="<f4")     # counter-clockwise on the y-down screen after clipping
+    back = np.array([A, B, C], dtype="<f4")
+    img = _draw(O, [front], w, h, model=model.reshape(16))
+    assert not _draw(O, [back], w, h, model=model.reshape(16)).any()
+    # clipped polygon in screen space: A, I(A,C), I(B,C), B with NDC depth 0.25 at A and B, 1.0 on the plane
+    pa, pac, pbc, pb = (4.0, 4.0), (0.0, 16.0), (16.0, 16.0), (12.0, 4.0)
+    want = np.maximum(_brute([pa, pac, pbc], [0.25, 1.0, 1.0], w, h), _brute([pa, pbc, pb], [0.25, 1.0, 0.25], w, h))
+    assert np.array_equal(img > 0, want > 0)
+    assert (img > 0).sum() > 100 and not (img[:4] > 0).any()
+    assert np.all(np.abs(img.astype(np.float64) - want) <= np.spacing(want.astype("<f4")).astype(np.float64))
+    # two vertices behind the plane: a single smaller triangle remains
+    tri1 = np.array([(-0.5, -0.5, 1.0), (0.0, 1.0, -0.5), (1.0, 1.0, -0.5)], dtype="<f4")
+    img1 = _draw(O, [tri1], w, h, model=model.reshape(16))
+    img1r = _draw(O, [tri1[[0, 2, 1]]], w, h, model=model.reshape(16))
+    assert (img1 > 0).any() != (img1r > 0).any()           # exactly one winding is front-facing
+    # everything behind: nothing
+    assert not _draw(O, [np.array([(0, 0, -1.0), (1, 0, -1.0), (0, 1, -1.0)], dtype="<f4")], w, h, model=model.reshape(16)).any()

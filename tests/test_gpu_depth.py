@@ -40,9 +40,9 @@ def test_two_phase_frame_kitten(mc, O, ctx, kitten, config1):
     assert 0 < ref2.total <= ref1.total
 
 
-def test_large_triangles_accumulation_and_eye_plane(mc, O, ctx, kitten, H):
+def test_large_triangles_accumulation_and_near_plane(mc, O, ctx, kitten, H):
     """Instances scaled up and pushed towards the camera: boxes of thousands of pixels (rasterised by
-    the whole wave), triangles crossing the eye plane (dropped), and a second pass accumulated into
+    the whole wave), triangles crossing the near plane (clipped), and a second pass accumulated into
     the same image with clear = 0."""
     w, h = 1920, 1080
     ml = kitten["meshlets"]

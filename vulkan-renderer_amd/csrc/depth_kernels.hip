@@ -6,10 +6,12 @@
 // (Engine.cpp:961-962), depth test GREATER_OR_EQUAL on a buffer cleared to 0 (Engine.cpp:975,:2404).
 // What a hardware rasteriser leaves implementation-defined is fixed here as: float edge functions
 // evaluated at pixel centres, top-left fill rule, screen-space barycentric depth, fragments outside
-// 0 <= z <= 1 dropped, triangles with a vertex at or behind the eye plane (w <= 0) dropped instead
-// of clipped.  Every expression fixes its association order (no fused multiply-add, correctly
-// rounded division), and the per-pixel result is a maximum, so the image is independent of the
-// order in which triangles arrive and equals a sequential evaluation bit for bit.
+// 0 <= z <= 1 dropped; triangles crossing the near plane z <= w are clipped in clip space
+// (Sutherland-Hodgman, intersections always evaluated from the inside vertex towards the outside one,
+// t = d_p / (d_p - d_q) with d = w - z), whatever then still has w <= 0 is dropped.  Every
+// expression fixes its association order (no fused multiply-add, correctly rounded division), and
+// the per-pixel result is a maximum, so the image is independent of the order in which triangles
+// arrive and equals a sequential evaluation bit for bit.
 //
 // One wave per visible (drawID, meshletID) entry: lane l projects local vertex l (a meshlet has at
 // most 64), triangles fetch their corners with lane shuffles, lane t rasterises triangle t and
@@ -39,6 +41,36 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
 __device__ __forceinline__ bool edge_top_left(float ax, float ay, float bx, float by) {
     const float dx = bx - ax, dy = by - ay;
     return dy > 0.0f || (dy == 0.0f && dx < 0.0f);
+}
+
+struct ClipV {
+    float x, y, z, w;
+};
+struct ScreenV {
+    float x, y, z;
+    int ok;
+};
+
+__device__ __forceinline__ ScreenV to_screen(const ClipV &c, float wf, float hf) {
+    ScreenV r;
+    r.ok = c.w > 0.0f;
+    const float nx = c.x / c.w, ny = c.y / c.w;
+    r.z = c.z / c.w;
+    r.x = (nx * 0.5f + 0.5f) * wf;  // viewport transform, Engine.cpp:2413-2420
+    r.y = (ny * 0.5f + 0.5f) * hf;
+    return r;
+}
+
+// intersection of the edge p -> q with the near plane, p inside (w - z >= 0), q outside
+__device__ __forceinline__ ClipV clip_intersect(const ClipV &p, const ClipV &q) {
+    const float dp = p.w - p.z, dq = q.w - q.z;
+    const float t = dp / (dp - dq);
+    ClipV r;
+    r.x = p.x + t * (q.x - p.x);
+    r.y = p.y + t * (q.y - p.y);
+    r.z = p.z + t * (q.z - p.z);
+    r.w = p.w + t * (q.w - p.w);
+    return r;
 }
 
 // one pixel of one front-facing triangle (area < 0)
@@ -79,21 +111,20 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
             for (int r = 0; r < 4; r++)
                 mvp[4 * c + r] = ((rc.vp[r] * mdl[4 * c] + rc.vp[4 + r] * mdl[4 * c + 1]) + rc.vp[8 + r] * mdl[4 * c + 2]) +
                                  rc.vp[12 + r] * mdl[4 * c + 3];
-        // lane l: local vertex l -> screen position
+        // lane l: local vertex l -> clip and screen position
+        ClipV cv = {0.0f, 0.0f, 0.0f, 0.0f};
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        int ok = 0;
+        int ok = 0, inside = 0;
         if (lane < vc) {
             const mcull_vertex *v = vertices + meshlet_data[off + lane];
             const float px = v->vx, py = v->vy, pz = v->vz;
-            const float cx = ((mvp[0] * px + mvp[4] * py) + mvp[8] * pz) + mvp[12];
-            const float cy = ((mvp[1] * px + mvp[5] * py) + mvp[9] * pz) + mvp[13];
-            const float cz = ((mvp[2] * px + mvp[6] * py) + mvp[10] * pz) + mvp[14];
-            const float cw = ((mvp[3] * px + mvp[7] * py) + mvp[11] * pz) + mvp[15];
-            ok = cw > 0.0f;
-            const float nx = cx / cw, ny = cy / cw;
-            sz = cz / cw;
-            sx = (nx * 0.5f + 0.5f) * rc.wf;
-            sy = (ny * 0.5f + 0.5f) * rc.hf;
+            cv.x = ((mvp[0] * px + mvp[4] * py) + mvp[8] * pz) + mvp[12];
+            cv.y = ((mvp[1] * px + mvp[5] * py) + mvp[9] * pz) + mvp[13];
+            cv.z = ((mvp[2] * px + mvp[6] * py) + mvp[10] * pz) + mvp[14];
+            cv.w = ((mvp[3] * px + mvp[7] * py) + mvp[11] * pz) + mvp[15];
+            const ScreenV sv = to_screen(cv, rc.wf, rc.hf);
+            sx = sv.x; sy = sv.y; sz = sv.z; ok = sv.ok;
+            inside = (cv.w - cv.z) >= 0.0f;  // in front of the near plane
         }
         const uint8_t *locals = reinterpret_cast<const uint8_t *>(meshlet_data + off + vc);
         for (uint32_t base = 0; base < tc; base += 64u) {  // wave-uniform trip count
@@ -104,46 +135,88 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
             tr.x0 = __shfl(sx, (int)i0); tr.y0 = __shfl(sy, (int)i0); tr.z0 = __shfl(sz, (int)i0);
             tr.x1 = __shfl(sx, (int)i1); tr.y1 = __shfl(sy, (int)i1); tr.z1 = __shfl(sz, (int)i1);
             tr.x2 = __shfl(sx, (int)i2); tr.y2 = __shfl(sy, (int)i2); tr.z2 = __shfl(sz, (int)i2);
-            const int all_ok = __shfl(ok, (int)i0) & __shfl(ok, (int)i1) & __shfl(ok, (int)i2);
-            const float area = (tr.x1 - tr.x0) * (tr.y2 - tr.y0) - (tr.x2 - tr.x0) * (tr.y1 - tr.y0);
-            bool draw = valid && all_ok && (area < 0.0f);  // front-facing, in front of the eye, not NaN
-            const float minx = fminf(fminf(tr.x0, tr.x1), tr.x2), maxx = fmaxf(fmaxf(tr.x0, tr.x1), tr.x2);
-            const float miny = fminf(fminf(tr.y0, tr.y1), tr.y2), maxy = fmaxf(fmaxf(tr.y0, tr.y1), tr.y2);
-            const float x_lo = fmaxf(ceilf(minx - 0.5f), 0.0f), x_hi = fminf(floorf(maxx - 0.5f), (float)(rc.w - 1u));
-            const float y_lo = fmaxf(ceilf(miny - 0.5f), 0.0f), y_hi = fminf(floorf(maxy - 0.5f), (float)(rc.h - 1u));
-            draw = draw && (x_lo <= x_hi) && (y_lo <= y_hi);
-            uint32_t bx = 0, by = 0, bw = 0, bh = 0;
-            if (draw) {
-                bx = (uint32_t)x_lo; by = (uint32_t)y_lo;
-                bw = (uint32_t)x_hi - bx + 1u; bh = (uint32_t)y_hi - by + 1u;
-            }
-            const bool tl0 = edge_top_left(tr.x1, tr.y1, tr.x2, tr.y2), tl1 = edge_top_left(tr.x2, tr.y2, tr.x0, tr.y0),
-                       tl2 = edge_top_left(tr.x0, tr.y0, tr.x1, tr.y1);
-            const uint64_t box = (uint64_t)bw * bh;
-            const bool small = draw && box <= kSmallBox;
-            if (small) {
-                for (uint32_t p = 0; p < (uint32_t)box; p++) {
-                    const uint32_t yy = p / bw, xx = p - yy * bw;
-                    raster_pixel(tr, area, tl0, tl1, tl2, bx + xx, by + yy, rc.w, depth_bits);
+            int tri_ok = __shfl(ok, (int)i0) & __shfl(ok, (int)i1) & __shfl(ok, (int)i2);
+            const int in0 = __shfl(inside, (int)i0), in1 = __shfl(inside, (int)i1), in2 = __shfl(inside, (int)i2);
+            const int n_in = in0 + in1 + in2;
+            // n_in == 3: the triangle as it is; 0: nothing; 1 or 2: clipped to a triangle or a quad (= two
+            // triangles fanned from the polygon's first vertex, polygon order as the edge walk 0->1->2->0 emits it)
+            const bool needs_clip = valid && n_in > 0 && n_in < 3;
+            Tri tr2 = tr;
+            int tri2_ok = 0;
+            bool second = false;
+            if (__any(needs_clip)) {  // wave-uniform: the shuffles below need every lane
+                ClipV v0, v1, v2;
+                v0.x = __shfl(cv.x, (int)i0); v0.y = __shfl(cv.y, (int)i0); v0.z = __shfl(cv.z, (int)i0); v0.w = __shfl(cv.w, (int)i0);
+                v1.x = __shfl(cv.x, (int)i1); v1.y = __shfl(cv.y, (int)i1); v1.z = __shfl(cv.z, (int)i1); v1.w = __shfl(cv.w, (int)i1);
+                v2.x = __shfl(cv.x, (int)i2); v2.y = __shfl(cv.y, (int)i2); v2.z = __shfl(cv.z, (int)i2); v2.w = __shfl(cv.w, (int)i2);
+                if (needs_clip) {
+                    const ClipV e0 = in0 ? clip_intersect(v0, v1) : clip_intersect(v1, v0);  // edge 0-1 (if it crosses)
+                    const ClipV e1 = in1 ? clip_intersect(v1, v2) : clip_intersect(v2, v1);  // edge 1-2
+                    const ClipV e2 = in2 ? clip_intersect(v2, v0) : clip_intersect(v0, v2);  // edge 2-0
+                    ClipV p0 = v0, p1 = v1, p2 = v2, p3 = v2;
+                    switch (in0 | (in1 << 1) | (in2 << 2)) {
+                        case 1: p0 = v0; p1 = e0; p2 = e2; break;
+                        case 2: p0 = e0; p1 = v1; p2 = e1; break;
+                        case 4: p0 = e1; p1 = v2; p2 = e2; break;
+                        case 3: p0 = v0; p1 = v1; p2 = e1; p3 = e2; second = true; break;
+                        case 6: p0 = e0; p1 = v1; p2 = v2; p3 = e2; second = true; break;
+                        default: p0 = v0; p1 = e0; p2 = e1; p3 = v2; second = true; break;  // 5
+                    }
+                    const ScreenV s0 = to_screen(p0, rc.wf, rc.hf), s1 = to_screen(p1, rc.wf, rc.hf), s2 = to_screen(p2, rc.wf, rc.hf),
+                                  s3 = to_screen(p3, rc.wf, rc.hf);
+                    tr.x0 = s0.x; tr.y0 = s0.y; tr.z0 = s0.z; tr.x1 = s1.x; tr.y1 = s1.y; tr.z1 = s1.z;
+                    tr.x2 = s2.x; tr.y2 = s2.y; tr.z2 = s2.z;
+                    tri_ok = s0.ok & s1.ok & s2.ok;
+                    tr2.x0 = s0.x; tr2.y0 = s0.y; tr2.z0 = s0.z; tr2.x1 = s2.x; tr2.y1 = s2.y; tr2.z1 = s2.z;
+                    tr2.x2 = s3.x; tr2.y2 = s3.y; tr2.z2 = s3.z;
+                    tri2_ok = s0.ok & s2.ok & s3.ok;
                 }
             }
-            // large boxes: the whole wave walks one triangle at a time
-            uint64_t big = __ballot(draw && !small);
-            while (big) {
-                const int src = __builtin_ctzll(big);
-                big &= big - 1ull;
-                Tri b;
-                b.x0 = __shfl(tr.x0, src); b.y0 = __shfl(tr.y0, src); b.z0 = __shfl(tr.z0, src);
-                b.x1 = __shfl(tr.x1, src); b.y1 = __shfl(tr.y1, src); b.z1 = __shfl(tr.z1, src);
-                b.x2 = __shfl(tr.x2, src); b.y2 = __shfl(tr.y2, src); b.z2 = __shfl(tr.z2, src);
-                const float b_area = __shfl(area, src);
-                const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
-                const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
-                           t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
-                const uint64_t cells = (uint64_t)ow * oh;
-                for (uint64_t p = lane; p < cells; p += 64u) {
-                    const uint32_t yy = (uint32_t)(p / ow), xx = (uint32_t)(p - (uint64_t)yy * ow);
-                    raster_pixel(b, b_area, t0, t1, t2, ox + xx, oy + yy, rc.w, depth_bits);
+            const bool first = valid && (n_in == 3 || needs_clip);
+            const int rounds = __any(second) ? 2 : 1;  // wave-uniform
+            for (int round = 0; round < rounds; round++) {
+                const Tri cur = round == 0 ? tr : tr2;
+                const bool cur_valid = round == 0 ? (first && tri_ok) : (second && tri2_ok);
+                const float area = (cur.x1 - cur.x0) * (cur.y2 - cur.y0) - (cur.x2 - cur.x0) * (cur.y1 - cur.y0);
+                bool draw = cur_valid && (area < 0.0f);  // front-facing, in front of the eye, not NaN
+                const float minx = fminf(fminf(cur.x0, cur.x1), cur.x2), maxx = fmaxf(fmaxf(cur.x0, cur.x1), cur.x2);
+                const float miny = fminf(fminf(cur.y0, cur.y1), cur.y2), maxy = fmaxf(fmaxf(cur.y0, cur.y1), cur.y2);
+                const float x_lo = fmaxf(ceilf(minx - 0.5f), 0.0f), x_hi = fminf(floorf(maxx - 0.5f), (float)(rc.w - 1u));
+                const float y_lo = fmaxf(ceilf(miny - 0.5f), 0.0f), y_hi = fminf(floorf(maxy - 0.5f), (float)(rc.h - 1u));
+                draw = draw && (x_lo <= x_hi) && (y_lo <= y_hi);
+                uint32_t bx = 0, by = 0, bw = 0, bh = 0;
+                if (draw) {
+                    bx = (uint32_t)x_lo; by = (uint32_t)y_lo;
+                    bw = (uint32_t)x_hi - bx + 1u; bh = (uint32_t)y_hi - by + 1u;
+                }
+                const bool tl0 = edge_top_left(cur.x1, cur.y1, cur.x2, cur.y2), tl1 = edge_top_left(cur.x2, cur.y2, cur.x0, cur.y0),
+                           tl2 = edge_top_left(cur.x0, cur.y0, cur.x1, cur.y1);
+                const uint64_t box = (uint64_t)bw * bh;
+                const bool small = draw && box <= kSmallBox;
+                if (small) {
+                    for (uint32_t p = 0; p < (uint32_t)box; p++) {
+                        const uint32_t yy = p / bw, xx = p - yy * bw;
+                        raster_pixel(cur, area, tl0, tl1, tl2, bx + xx, by + yy, rc.w, depth_bits);
+                    }
+                }
+                // large boxes: the whole wave walks one triangle at a time
+                uint64_t big = __ballot(draw && !small);
+                while (big) {
+                    const int src = __builtin_ctzll(big);
+                    big &= big - 1ull;
+                    Tri b;
+                    b.x0 = __shfl(cur.x0, src); b.y0 = __shfl(cur.y0, src); b.z0 = __shfl(cur.z0, src);
+                    b.x1 = __shfl(cur.x1, src); b.y1 = __shfl(cur.y1, src); b.z1 = __shfl(cur.z1, src);
+                    b.x2 = __shfl(cur.x2, src); b.y2 = __shfl(cur.y2, src); b.z2 = __shfl(cur.z2, src);
+                    const float b_area = __shfl(area, src);
+                    const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
+                    const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
+                               t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
+                    const uint64_t cells = (uint64_t)ow * oh;
+                    for (uint64_t p = lane; p < cells; p += 64u) {
+                        const uint32_t yy = (uint32_t)(p / ow), xx = (uint32_t)(p - (uint64_t)yy * ow);
+                        raster_pixel(b, b_area, t0, t1, t2, ox + xx, oy + yy, rc.w, depth_bits);
+                    }
                 }
             }
         }
