@@ -176,3 +176,99 @@ def meshlet_cone(vertices_pos, meshlet_data, data_offset, vertex_count, triangle
             if mx < d2[i]:
                 mx = d2[i]
     return np.array([axis[0], axis[1], axis[2], cone_w], dtype=f32), apex, np.sqrt(mx, dtype=f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# depth pre-pass stand-in (Engine.cpp:2397-2441, shader.mesh:60-101), written separately from the C
+# oracle: one triangle at a time, pixels of its box evaluated as arrays.
+
+def _to_screen(c, wf, hf):
+    with np.errstate(all="ignore"):
+        nx, ny, z = c[0] / c[3], c[1] / c[3], c[2] / c[3]
+        return (nx * f32(0.5) + f32(0.5)) * wf, (ny * f32(0.5) + f32(0.5)) * hf, z, bool(c[3] > 0)
+
+
+def _isect(p, q):
+    """Edge p -> q against the near plane z <= w, p inside: p + t (q - p), t = d_p / (d_p - d_q)."""
+    with np.errstate(all="ignore"):
+        dp, dq = p[3] - p[2], q[3] - q[2]
+        t = dp / (dp - dq)
+        return p + t * (q - p)
+
+
+def _raster(depth_bits, a, b, c, w, h):
+    (ax, ay, az, aok), (bx, by, bz, bok), (cx, cy, cz, cok) = a, b, c
+    if not (aok and bok and cok):
+        return
+    with np.errstate(all="ignore"):
+        area = (bx - ax) * (cy - ay) - (cx - ax) * (by - ay)
+        if not area < 0:
+            return
+        xs, ys = np.array([ax, bx, cx], dtype=f32), np.array([ay, by, cy], dtype=f32)
+        if np.isnan(xs).any() or np.isnan(ys).any():
+            lo_x, hi_x, lo_y, hi_y = f32(0), f32(w - 1), f32(0), f32(h - 1)  # fmin/fmax ignore NaN operands
+            fx, fy = xs[~np.isnan(xs)], ys[~np.isnan(ys)]
+            if len(fx):
+                lo_x, hi_x = max(np.ceil(fx.min() - f32(0.5)), f32(0)), min(np.floor(fx.max() - f32(0.5)), f32(w - 1))
+            if len(fy):
+                lo_y, hi_y = max(np.ceil(fy.min() - f32(0.5)), f32(0)), min(np.floor(fy.max() - f32(0.5)), f32(h - 1))
+        else:
+            lo_x, hi_x = max(np.ceil(xs.min() - f32(0.5)), f32(0)), min(np.floor(xs.max() - f32(0.5)), f32(w - 1))
+            lo_y, hi_y = max(np.ceil(ys.min() - f32(0.5)), f32(0)), min(np.floor(ys.max() - f32(0.5)), f32(h - 1))
+        if not (lo_x <= hi_x and lo_y <= hi_y):
+            return
+        px = np.arange(int(lo_x), int(hi_x) + 1, dtype=np.int64)
+        py = np.arange(int(lo_y), int(hi_y) + 1, dtype=np.int64)
+        X = (px.astype(f32) + f32(0.5))[None, :]
+        Y = (py.astype(f32) + f32(0.5))[:, None]
+
+        def edge(x0, y0, x1, y1):
+            return (x1 - x0) * (Y - y0) - (y1 - y0) * (X - x0)
+
+        def top_left(x0, y0, x1, y1):
+            dx, dy = x1 - x0, y1 - y0
+            return bool(dy > 0 or (dy == 0 and dx < 0))
+
+        w0, w1, w2 = edge(bx, by, cx, cy), edge(cx, cy, ax, ay), edge(ax, ay, bx, by)
+        inside = ((w0 < 0) | ((w0 == 0) & top_left(bx, by, cx, cy))) & ((w1 < 0) | ((w1 == 0) & top_left(cx, cy, ax, ay))) & \
+                 ((w2 < 0) | ((w2 == 0) & top_left(ax, ay, bx, by)))
+        z = ((w0 * az + w1 * bz) + w2 * cz) / area
+        keep = inside & (z >= 0) & (z <= 1)
+        bits = z.astype(f32).view(np.uint32) & np.uint32(0x7FFFFFFF)
+        sub = depth_bits[py[0]:py[-1] + 1, px[0]:px[-1] + 1]
+        np.maximum(sub, np.where(keep, bits, np.uint32(0)), out=sub)
+
+
+def rasterize_depth(vertices_pos, meshlet_data, meshlets, transforms, visible, view, proj, w, h):
+    """vertices_pos (n,3) f32; meshlets: structured array with dataOffset/vertexCount/triangleCount;
+    transforms (n,16); visible: (drawID, meshletID) pairs.  Returns the (h, w) float32 image."""
+    vp = mat_mul(proj, view)
+    depth_bits = np.zeros((h, w), dtype=np.uint32)
+    wf, hf = f32(w), f32(h)
+    for draw, mid in visible:
+        m = meshlets[int(mid)]
+        off, vc, tc = int(m["dataOffset"]), int(m["vertexCount"]), int(m["triangleCount"])
+        mvp = mat_mul(vp, transforms[int(draw)]).reshape(4, 4)  # [col][row]
+        pos = vertices_pos[meshlet_data[off:off + vc]]
+        clip = ((mvp[0][None, :] * pos[:, 0:1] + mvp[1][None, :] * pos[:, 1:2]) + mvp[2][None, :] * pos[:, 2:3]) + mvp[3][None, :]
+        local = meshlet_data[off + vc: off + vc + (3 * tc + 3) // 4].view(np.uint8)[: 3 * tc].reshape(tc, 3)
+        for tri in local:
+            v = [clip[int(i)] for i in tri]
+            inn = [bool((p[3] - p[2]) >= 0) for p in v]
+            if not any(inn):
+                continue
+            if all(inn):
+                poly = v
+            else:
+                poly = []
+                for k in range(3):
+                    q = (k + 1) % 3
+                    if inn[k]:
+                        poly.append(v[k])
+                    if inn[k] != inn[q]:
+                        poly.append(_isect(v[k], v[q]) if inn[k] else _isect(v[q], v[k]))
+            s = [_to_screen(p, wf, hf) for p in poly]
+            _raster(depth_bits, s[0], s[1], s[2], w, h)
+            if len(s) == 4:
+                _raster(depth_bits, s[0], s[2], s[3], w, h)
+    return depth_bits.view(f32)
