@@ -181,3 +181,38 @@ def test_frame_can_be_captured_as_a_hip_graph(mc, O, kitten, config1):
     assert c.download_list().tobytes() == want_list.tobytes()
     assert np.array_equal(c.depth_download().view("<u4"), want_depth.view("<u4"))
     c.close()
+
+
+def test_adversarial_vertices(mc, O, ctx, kitten, H):
+    """NaN / infinite / huge vertex positions and singular or NaN transforms: the image still equals
+    the oracle's bit for bit (such triangles produce NaN areas or depths and draw nothing, or cover
+    the whole screen box and are filtered per pixel)."""
+    rs = np.random.RandomState(12)
+    ml = kitten["meshlets"]
+    verts = kitten["vertices"].copy()
+    special = np.array([np.nan, np.inf, -np.inf, 3.0e38, -3.0e38, 1e-40, 0.0, -0.0], dtype="<f4")
+    for i in rs.choice(len(verts), 300, replace=False):
+        verts["pos"][i, rs.randint(0, 3)] = special[rs.randint(len(special))]
+    n = 40
+    t = H.update_transforms(n)
+    m = t["model"].reshape(n, 4, 4).copy()
+    m[2, :3, :3] = 0.0
+    m[5, 1, 1] = np.nan
+    m[9, :3, :3] *= np.float32(30.0)
+    m[9, 3, :3] = [2.0, 2.0, 2.0]
+    m[12, 3, 2] = np.inf
+    t["model"] = m.reshape(n, 16)
+    w, h = 96, 64
+    g = H.create_globals(width=w, height=h, meshlet_count=len(ml))
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(ml)
+    ctx.upload_geometry(verts, kitten["meshlet_data"])
+    ctx.upload_transforms(t)
+    with np.errstate(all="ignore"):
+        ref = O.cull_scene(O.View(g), t, ml, tests=0)
+        ctx.cull(g, tests=0)
+        ctx.depth_rasterize(g, w, h)
+        want = O.rasterize_depth(verts, kitten["meshlet_data"], ml, t, ref.list, g, w, h)
+    got = ctx.depth_download()
+    assert np.array_equal(_bits(got), _bits(want))
+    assert (want > 0).any() and not np.isnan(want).any()

@@ -407,3 +407,52 @@ def test_rebase_commands(mc, O, ctx, kitten, config1):
     # the ordered cull after the rebases still starts from clean tile counters
     ctx.cull(g, tests=3)
     assert ctx.download_list().tobytes() == ref.list.tobytes()
+
+
+def test_adversarial_bounds_and_transforms(mc, O, ctx, H):
+    """NaN / infinite / denormal bounds, zero and negative radii, zero-length and NaN axes, coneW at
+    and beyond its range, singular / NaN / mirrored transforms, spheres at the eye and on the planes:
+    every test combination must still agree with the oracle bit for bit."""
+    rs = np.random.RandomState(99)
+    n_inst, per = 96, 192
+    cone, sphere = H.synthetic_bounds(n_inst * per, seed=7)
+    cone = cone.copy(); sphere = sphere.copy()
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-40, -1e-40, 3.4e38, -3.4e38, 1.0, -1.0, 0.5], dtype="<f4")
+    idx = rs.choice(n_inst * per, 4000, replace=False)
+    for k, i in enumerate(idx):
+        if k % 2 == 0:
+            cone[i, rs.randint(0, 4)] = special[rs.randint(len(special))]
+        else:
+            sphere[i, rs.randint(0, 4)] = special[rs.randint(len(special))]
+    cone[idx[:200], :3] = 0.0                       # zero axis -> NaN after normalisation -> never cone-culled
+    sphere[idx[200:300], 3] = -sphere[idx[200:300], 3]
+    t = H.synthetic_transforms(n_inst, extent=20.0, seed=5)
+    m = t["model"].reshape(n_inst, 4, 4).copy()
+    m[3, :3, :3] = 0.0                              # singular
+    m[7, 0, 0] = np.nan
+    m[11, :3, :3] *= np.float32(-2.5)               # mirrored + scaled
+    m[13, 3, :3] = [2.0, 2.0, 2.0]                  # at the eye
+    m[17, :3, :3] *= np.float32(1e-30)
+    m[19, 3, 0] = np.inf
+    t["model"] = m.reshape(n_inst, 16)
+    off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+    cnt = np.full(n_inst, per, dtype="<u4")
+    w, h = 256, 128
+    depth = H.synthetic_depth(w, h, n_discs=12, seed=4)
+    depth.flat[rs.randint(0, w * h, 50)] = np.nan
+    ctx.upload_bounds_soa(cone, sphere)
+    ctx.upload_transforms(t)
+    ctx.set_instance_ranges(off, cnt)
+    ctx.hiz_build(depth, view=4)
+    pyr = O.hiz_build(depth)
+    with np.errstate(all="ignore"):
+        for flip in (True, False):
+            g = H.create_globals(eye=(2.0, 2.0, 2.0), width=w, height=h, flip_y=flip)
+            view = O.View(g, pyr, w, h)
+            for tests in (7, 5, 6, 3, 4):
+                ref = O.cull_scene(view, t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=tests)
+                for compaction in (0, 1):
+                    ctx.cull(g, tests=tests, hiz_view=4, compaction=compaction, write_mask=True)
+                    assert np.array_equal(ctx.download_mask(), ref.mask), (flip, tests, compaction)
+                    check_against_oracle(mc, ctx, ref, n_inst, compaction)
+    ctx.set_instance_ranges(None, None)
