@@ -93,3 +93,32 @@ def test_gpu_mesh_errors(mc, ctx):
     empty = ctx.mesh_from_arrays(pos, np.zeros((0, 3), "<i4"))
     ctx.build_meshlets(empty)
     assert len(empty.meshlets) == 0 and len(empty.vertices) == 0
+
+
+def test_bounds_with_adversarial_vertices(mc, O, ctx, kitten):
+    """buildMeshletCon on the GPU with NaN / infinite / denormal / huge positions and degenerate
+    triangles: cone, apex and radius still equal the scalar CPU loop bit for bit, a NaN matching any
+    NaN."""
+    rs = np.random.RandomState(3)
+    verts = kitten["vertices"].copy()
+    special = np.array([np.nan, np.inf, -np.inf, 3.0e38, -3.0e38, 1e-40, -1e-40, 0.0, -0.0], dtype="<f4")
+    for i in rs.choice(len(verts), 400, replace=False):
+        verts["pos"][i, rs.randint(0, 3)] = special[rs.randint(len(special))]
+    for i in rs.choice(len(verts) - 1, 200, replace=False):   # coincident vertices -> zero-area triangles
+        verts["pos"][i] = verts["pos"][i + 1]
+    blank = kitten["meshlets"].copy()
+    blank["cone"] = 0; blank["coneApex"] = 0; blank["radius"] = 0
+    with np.errstate(all="ignore"):
+        want = O.build_meshlet_cones(verts, kitten["meshlet_data"], blank)
+    ctx.upload_meshlets(blank)
+    ctx.upload_geometry(verts, kitten["meshlet_data"])
+    ctx.compute_bounds()
+    got = ctx.download_meshlets(len(blank))
+    def same(a, b):  # NaN equals NaN (sign and payload of a NaN are not part of the contract); everything else bit for bit
+        a, b = np.asarray(a, dtype="<f4").reshape(-1), np.asarray(b, dtype="<f4").reshape(-1)
+        return bool(np.all((a.view("<u4") == b.view("<u4")) | (np.isnan(a) & np.isnan(b))))
+
+    bad = [(i, f) for i in range(len(blank)) for f in ("cone", "coneApex", "radius") if not same(got[i][f], want[i][f])]
+    assert not bad, (bad[:8], [(got[i][f], want[i][f]) for i, f in bad[:4]])
+    n_nan = sum(1 for i in range(len(blank)) if np.isnan(want[i]["cone"]).any() or np.isnan(want[i]["radius"]))
+    assert n_nan > 20
