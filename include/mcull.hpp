@@ -13,6 +13,7 @@
 //   vkCmdPushConstants + vkCmdDrawMeshTasksIndirectNV :2535-2539   Culler::cull
 //   createIndirectBuffer         :1466-1506    written by Culler::cull (dynamic)
 //   depth pre-pass               :2397-2441    Culler::rasterizeDepth (software rasteriser over the visible list)
+//   recordCmdBuffer              :2381-2551    Culler::recordFrame (pre-pass cull -> depth -> pyramid -> main-pass cull)
 //   loadModel                    :243-282      Mesh::loadModel
 //   optimizeGeometry             :338-471      Mesh::optimizeGeometry
 //   createMeshlets               :548-628      Mesh::createMeshlets (host) / Culler::createMeshlets (GPU, with bounds)
@@ -165,6 +166,22 @@ public:
         const float *ptr = nullptr;
         MCULL_CHECK(ctx_, mcull_depth_buffer(ctx_, &ptr, nullptr, nullptr));
         return ptr;
+    }
+    // The culling work of one recorded frame (Engine::recordCmdBuffer): the pre-pass cull, the depth
+    // pre-pass over its survivors, the pyramid built from that depth, and the main-pass cull with all
+    // three tests.  The reference's pre-pass runs the same task shader against the pyramid left by the
+    // previous frame; pass prepass_tests = MCULL_TEST_ALL for that, the default leaves occlusion out
+    // of the pre-pass so that the first frame needs no history.  Returns the main-pass result.
+    mcull_cull_result recordFrame(const Globals &globals, uint32_t width, uint32_t height,
+                                  uint32_t prepass_tests = MCULL_TEST_FRUSTUM | MCULL_TEST_CONE, uint32_t view = 0) {
+        mcull_cull_params p{};
+        p.tests = prepass_tests;
+        p.hiz_view = view;
+        cull(globals, &p);
+        const float *depth = rasterizeDepth(globals, width, height);
+        buildHiZPyramid(depth, width, height, view, /*on_device=*/true);
+        p.tests = MCULL_TEST_ALL;
+        return cull(globals, &p);
     }
     // scene cache: the arrays of Engine.hpp:215-218 written once, uploaded from the file afterwards
     static void saveScene(const std::string &path, const std::vector<Vertex> &vertices, const std::vector<uint32_t> &indices,
