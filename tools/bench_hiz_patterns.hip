@@ -29,6 +29,12 @@ __global__ __launch_bounds__(64) void per_level_kernel(const float *__restrict__
     }
 }
 
+// streaming floor: level 0 alone (a non-temporal copy of the depth image)
+__global__ __launch_bounds__(256) void copy_floor_kernel(const f4v *__restrict__ src, f4v *__restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const uint32_t sizes[][2] = {{800, 600}, {1280, 720}, {1920, 1080}, {2560, 1440}, {3840, 2160}, {4096, 4096}, {7680, 4320}, {8192, 8192}};
@@ -61,6 +67,11 @@ int main() {
         };
         timeit("single launch (tiles + last-arriver tail)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, true, 0)); });
         timeit("two launches (tiles, then top levels)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, false, 0)); });
+        if (w % 4 == 0)
+            timeit("floor: non-temporal copy of level 0 only", [&] {
+                const size_t n4 = (size_t)w * h / 4;
+                hipLaunchKernelGGL(copy_floor_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, 0, (const f4v *)depth, (f4v *)pyr, n4);
+            });
         timeit("reference scheme: one dispatch per level", [&] {
             for (uint32_t i = 0; i < levels; i++) {
                 const float *src = i == 0 ? depth : pyr_ref + tbl[32 + i - 1];
