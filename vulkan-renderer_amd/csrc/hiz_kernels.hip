@@ -6,7 +6,8 @@
 // level k-1; level extents are max(1, w>>k) x max(1, h>>k).  Because floor division composes,
 // every texel of level k depends only on its own aligned 2^k x 2^k block of level 0, so one
 // workgroup can produce levels 0..6 of a 64x64 tile from a single read of the depth image:
-// levels 1-2 in registers (4x4 texels per thread), 3-6 through LDS.  Each workgroup contributes
+// levels 1-2 in registers (4x4 texels per thread), level 3 from LDS and 4-6 with lane shuffles by
+// the workgroup's first wave.  Each workgroup contributes
 // exactly one level-6 texel; the remaining levels are reduced inside the same launch by the waves
 // that finish last (two tiers of atomic tickets, write-through stores + agent-scope acquire).  min() is written as (y < x ? y : x), GLSL's
 // definition, so the result is bit-identical to the level-by-level evaluation for every input
@@ -62,45 +63,6 @@ __global__ __launch_bounds__(kBlock) void hiz_generic_kernel(const float *__rest
     }
 }
 
-// Levels base+1 .. base+4 of one 16x16 block of level `base` held in s2, through LDS (8x8, 4x4, 2x2, 1).
-// origin_x/y = level-0 coordinates of the block.  Child indices clamp to the last valid texel of the
-// source level inside the block (a no-op unless one image dimension has collapsed to 1).  With
-// WT_LAST the single texel of level base+4 is stored write-through at agent scope, because another
-// workgroup will read it in the same launch.
-template <bool WT_LAST>
-__device__ __forceinline__ void lds_levels(float (*s2)[17], float (*s3)[9], float (*s4)[5], float (*s5)[3],
-                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl, uint32_t levels,
-                                           uint32_t base, uint32_t origin_x, uint32_t origin_y, uint32_t t) {
-#define HIZ_LDS_LEVEL(STEP, SRC, DST, N, WT)                                                                    \
-    if (levels > base + (STEP)) {                                                                               \
-        const uint32_t K = base + (STEP);                                                                       \
-        if (t < (N) * (N)) {                                                                                    \
-            const uint32_t x = t % (N), y = t / (N);                                                            \
-            const uint32_t sw = tbl[K - 1], sh = tbl[16 + K - 1];                                               \
-            const uint32_t ox = origin_x >> (K - 1), oy = origin_y >> (K - 1);                                  \
-            const uint32_t mx = sw > ox ? min(sw - 1 - ox, 2u * (N)-1u) : 0u;                                   \
-            const uint32_t my = sh > oy ? min(sh - 1 - oy, 2u * (N)-1u) : 0u;                                   \
-            const uint32_t cx0 = min(2 * x, mx), cx1 = min(2 * x + 1, mx);                                      \
-            const uint32_t cy0 = min(2 * y, my), cy1 = min(2 * y + 1, my);                                      \
-            const float v = min4(SRC[cy0][cx0], SRC[cy0][cx1], SRC[cy1][cx0], SRC[cy1][cx1]);                   \
-            DST;                                                                                                \
-            const uint32_t lw = tbl[K], lh = tbl[16 + K];                                                       \
-            const uint32_t gx = (origin_x >> K) + x, gy = (origin_y >> K) + y;                                  \
-            if (gx < lw && gy < lh) {                                                                           \
-                float *dst = pyr + tbl[32 + K] + (size_t)gy * lw + gx;                                          \
-                if (WT) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 \
-                else *dst = v;                                                                                  \
-            }                                                                                                   \
-        }                                                                                                       \
-        __syncthreads();                                                                                        \
-    }
-    HIZ_LDS_LEVEL(1, s2, s3[y][x] = v, 8, false)
-    HIZ_LDS_LEVEL(2, s3, s4[y][x] = v, 4, false)
-    HIZ_LDS_LEVEL(3, s4, s5[y][x] = v, 2, false)
-    HIZ_LDS_LEVEL(4, s5, (void)0, 1, WT_LAST)
-#undef HIZ_LDS_LEVEL
-}
-
 // Texels handed from one workgroup to another inside a launch are stored write-through and read
 // back with agent-scope loads, which are served coherently across the XCDs' L2s.  That keeps the
 // hand-off free of cache-wide operations: an acquire fence would invalidate the reader's whole L2
@@ -144,9 +106,6 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
                                                           uint32_t levels, uint32_t *__restrict__ counter) {
     __shared__ float s2[16][17];
-    __shared__ float s3[8][9];
-    __shared__ float s4[4][5];
-    __shared__ float s5[2][3];
     const uint32_t t = threadIdx.x, tx = t & 15u, ty = t >> 4;
     const uint32_t x0 = blockIdx.x * kTile + 4 * tx, y0 = blockIdx.y * kTile + 4 * ty;
 
@@ -203,8 +162,26 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     s2[ty][tx] = q2;
     __syncthreads();
 
-    // ---- levels 3..6 through LDS
-    lds_levels<SINGLE_PASS>(s2, s3, s4, s5, pyr, tbl, levels, 2u, blockIdx.x * kTile, blockIdx.y * kTile, t);
+    // ---- levels 3..6: the 16x16 level-2 values are in LDS; from here on 64 lanes suffice, so waves
+    // 1-3 leave (their wave slots go to the next workgroup's loads) and wave 0 reduces level 3 from
+    // LDS and levels 4-6 with lane shuffles, without any further workgroup barrier.
+    if (t >= 64u) return;
+    if (levels > 3) {
+        const uint32_t ox2 = (blockIdx.x * kTile) >> 2, oy2 = (blockIdx.y * kTile) >> 2;  // tile origin in level 2
+        const uint32_t x = t & 7u, y = t >> 3;
+        const uint32_t sw = tbl[2], sh = tbl[16 + 2];
+        // child indices clamp to the last valid texel of level 2 inside the tile (matters only when
+        // that extent has collapsed to 1)
+        const uint32_t mx = sw > ox2 ? min(sw - 1u - ox2, 15u) : 0u, my = sh > oy2 ? min(sh - 1u - oy2, 15u) : 0u;
+        const uint32_t cx0 = min(2u * x, mx), cx1 = min(2u * x + 1u, mx), cy0 = min(2u * y, my), cy1 = min(2u * y + 1u, my);
+        float v = min4(s2[cy0][cx0], s2[cy0][cx1], s2[cy1][cx0], s2[cy1][cx1]);
+        const uint32_t lw = tbl[3], lh = tbl[16 + 3];
+        const uint32_t gx3 = (ox2 >> 1) + x, gy3 = (oy2 >> 1) + y;
+        if (gx3 < lw && gy3 < lh) pyr[tbl[32 + 3] + (size_t)gy3 * lw + gx3] = v;
+        v = wave_level<8, false>(v, 4u, levels, ox2 >> 2, oy2 >> 2, pyr, tbl, t);
+        v = wave_level<4, false>(v, 5u, levels, ox2 >> 3, oy2 >> 3, pyr, tbl, t);
+        v = wave_level<2, SINGLE_PASS>(v, 6u, levels, ox2 >> 4, oy2 >> 4, pyr, tbl, t);
+    }
 
     if (!SINGLE_PASS || levels <= 7) return;
 
@@ -219,7 +196,6 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     // L2 write-back or invalidate is needed on either side, and no
     // word receives more than 256 tickets (a single word sustains only ~90 returning atomics per
     // microsecond, which 16 384 workgroups would queue on).
-    if (t >= 64u) return;
     const uint32_t gx = blockIdx.x >> 3, gy = blockIdx.y >> 3;
     const uint32_t groups_x = (gridDim.x + 7u) >> 3, groups_y = (gridDim.y + 7u) >> 3;
     uint32_t last = 0u;
