@@ -94,29 +94,57 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     const mcull_vertex *__restrict__ vertices, const float *__restrict__ transforms, RasterConst rc,
     uint32_t *__restrict__ depth_bits) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * (kRasterBlock / 64) + (threadIdx.x >> 6);
+    // the wave index is made provably wave-uniform, so that the list entry, the meshlet header and
+    // the matrix are fetched with scalar loads into SGPRs
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kRasterBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (kRasterBlock / 64);
     unsigned long long n = *total;
     if (n > capacity) n = capacity;
+    if (wave0 >= n) return;
+    struct Hdr {
+        uint32_t off, vc, tc;
+    };
+    auto load_entry = [&](uint64_t i) { return list[i < n ? i : n - 1]; };  // past the end: a valid entry that is never processed
+    auto load_header = [&](const mcull_visible &en) {
+        const mcull_meshlet *m = meshlets + en.meshletID;
+        return Hdr{m->dataOffset, m->vertexCount, m->triangleCount};
+    };
+    auto load_vertex_id = [&](const Hdr &hd) { return lane < hd.vc ? meshlet_data[hd.off + lane] : 0u; };
+    // Software pipeline over the dependent loads entry -> header -> vertex id -> vertex: the entry is
+    // fetched three iterations ahead, the header two, the vertex id one, so that an iteration waits
+    // for a single memory round trip (the vertex itself) instead of four.
+    mcull_visible ent_a = load_entry(wave0), ent_b = load_entry(wave0 + n_waves), ent_c = load_entry(wave0 + 2 * n_waves);
+    Hdr hdr_a = load_header(ent_a), hdr_b = load_header(ent_b);
+    uint32_t gid_a = load_vertex_id(hdr_a);
     for (uint64_t e = wave0; e < n; e += n_waves) {
-        const mcull_visible ent = list[e];
-        const mcull_meshlet *m = meshlets + ent.meshletID;
-        const uint32_t off = m->dataOffset, vc = m->vertexCount, tc = m->triangleCount;
-        // mvp = (proj*view) * model, the element sum in the order k = 0..3
-        const float *mdl = transforms + (size_t)ent.drawID * 16;
+        const mcull_visible ent_d = load_entry(e + 3 * n_waves);
+        const Hdr hdr_c = load_header(ent_c);
+        const uint32_t gid_b = load_vertex_id(hdr_b);
+        const mcull_visible ent = ent_a;
+        const uint32_t off = hdr_a.off, vc = hdr_a.vc, tc = hdr_a.tc, gid = gid_a;
+        ent_a = ent_b; ent_b = ent_c; ent_c = ent_d;
+        hdr_a = hdr_b; hdr_b = hdr_c;
+        gid_a = gid_b;
+        // mvp = (proj*view) * model, the element sum in the order k = 0..3: lane i < 16 evaluates element
+        // i = 4*c + r, and the sixteen results are broadcast into SGPRs
         float mvp[16];
+        {
+            const uint32_t r = lane & 3u, c = (lane >> 2) & 3u;
+            const float4 col = *reinterpret_cast<const float4 *>(transforms + (size_t)ent.drawID * 16 + 4 * c);
+            const float a0 = r == 0 ? rc.vp[0] : r == 1 ? rc.vp[1] : r == 2 ? rc.vp[2] : rc.vp[3];
+            const float a1 = r == 0 ? rc.vp[4] : r == 1 ? rc.vp[5] : r == 2 ? rc.vp[6] : rc.vp[7];
+            const float a2 = r == 0 ? rc.vp[8] : r == 1 ? rc.vp[9] : r == 2 ? rc.vp[10] : rc.vp[11];
+            const float a3 = r == 0 ? rc.vp[12] : r == 1 ? rc.vp[13] : r == 2 ? rc.vp[14] : rc.vp[15];
+            const float el = ((a0 * col.x + a1 * col.y) + a2 * col.z) + a3 * col.w;
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                mvp[4 * c + r] = ((rc.vp[r] * mdl[4 * c] + rc.vp[4 + r] * mdl[4 * c + 1]) + rc.vp[8 + r] * mdl[4 * c + 2]) +
-                                 rc.vp[12 + r] * mdl[4 * c + 3];
+            for (int j = 0; j < 16; j++) mvp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(el), j));
+        }
         // lane l: local vertex l -> clip and screen position
         ClipV cv = {0.0f, 0.0f, 0.0f, 0.0f};
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         int ok = 0, inside = 0;
         if (lane < vc) {
-            const mcull_vertex *v = vertices + meshlet_data[off + lane];
+            const mcull_vertex *v = vertices + gid;
             const float px = v->vx, py = v->vy, pz = v->vz;
             cv.x = ((mvp[0] * px + mvp[4] * py) + mvp[8] * pz) + mvp[12];
             cv.y = ((mvp[1] * px + mvp[5] * py) + mvp[9] * pz) + mvp[13];
