@@ -554,8 +554,8 @@ def run_config1(env):
     z = np.load(os.path.join(ROOT, "tests", "golden", "kitten_scene.npz"))
     ml, md, vt = z["meshlets"].view(mc.MESHLET), z["meshlet_data"], z["vertices"].view(mc.VERTEX)
     n_inst, w, h = 1000, 800, 600
-    t = env.host.update_transforms(n_inst)
-    g = env.host.create_globals(width=w, height=h, meshlet_count=len(ml))
+    t = mc.reference_transforms(n_inst)  # the library's own updateTransforms / createGlobals (host code)
+    g = mc.create_globals(w, h, len(ml))
     ctx.upload_meshlets(ml)
     ctx.upload_geometry(vt, md)
     ctx.upload_transforms(t)

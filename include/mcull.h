@@ -383,6 +383,28 @@ int mcull_mesh_build_meshlets_gpu(mcull_ctx *ctx, mcull_mesh *mesh);
 int mcull_mesh_save(const mcull_mesh *mesh, const char *path);
 void mcull_mesh_destroy(mcull_mesh *mesh);
 
+/* ------------------------------------------------------------------ per-frame host inputs */
+
+/* Host code (no context, no GPU): the buffers the reference's Engine prepares on the CPU and hands
+ * to the path.  IEEE binary32 in glm's association order.
+ *
+ * createGlobals (Engine.cpp:2323-2352): lookAt view, infinite-far reverse-Z projection with
+ * proj[1][1] negated when flip_y != 0 (Engine.cpp:2335), meshletCount, and the five normalised
+ * frustum planes.  NULL eye/centre/up select the reference's camera: (2,2,2) -> origin, +Z up; the
+ * reference's remaining values are fov_deg 45, z_near 0.1, flip_y 1. */
+int mcull_create_globals(const float eye[3], const float centre[3], const float up[3], float fov_deg, float z_near,
+                         uint32_t width, uint32_t height, int flip_y, uint32_t meshlet_count, mcull_globals *out);
+/* The plane extraction alone (Engine.cpp:2337-2349) from the view and proj already stored in g. */
+int mcull_extract_frustum(mcull_globals *g);
+/* updateTransforms (Engine.cpp:2353-2377): draw_count model matrices from glibc's rand() sequence after
+ * srand(seed) (the reference uses 42), generated on a private generator state: the process-wide
+ * rand() is left untouched. */
+int mcull_reference_transforms(uint32_t draw_count, uint32_t seed, mcull_transform *out);
+/* createIndirectBuffer (Engine.cpp:1466-1484): the static commands the reference uploads once,
+ * taskCount = ceil(meshlet_count / 32), firstTask = 0.  mcull_cull writes the dynamic ones. */
+int mcull_create_indirect_buffer(uint32_t draw_count, uint32_t meshlet_count, uint32_t index_count,
+                                 mcull_draw_indirect *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,9 @@
 //   vkCmdPushConstants + vkCmdDrawMeshTasksIndirectNV :2535-2539   Culler::cull
 //   createIndirectBuffer         :1466-1506    written by Culler::cull (dynamic)
 //   depth pre-pass               :2397-2441    Culler::rasterizeDepth (software rasteriser over the visible list)
+//   createGlobals                :2323-2352    mcull::createGlobals
+//   updateTransforms (generation):2353-2377    mcull::referenceTransforms
+//   createIndirectBuffer (static):1466-1484    mcull::createIndirectBuffer
 //   recordCmdBuffer              :2381-2551    Culler::recordFrame (pre-pass cull -> depth -> pyramid -> main-pass cull)
 //   loadModel                    :243-282      Mesh::loadModel
 //   optimizeGeometry             :338-471      Mesh::optimizeGeometry
@@ -53,6 +56,29 @@ using Visible = mcull_visible;
 static_assert(sizeof(Vertex) == 24 && sizeof(Meshlet) == 48 && sizeof(Globals) == 212 && sizeof(Transform) == 64 &&
                   sizeof(DrawMeshTasksIndirectCommandNV) == 8 && sizeof(DrawMeshTasksIndirectCommandEXT) == 12 && sizeof(DrawIndirect) == 28 && sizeof(Visible) == 8,
               "layout contract of shaders/common.h / Engine.hpp");
+
+// Engine::createGlobals (Engine.cpp:2323-2352) for a width x height target; the defaults are the
+// reference's camera, field of view and near plane.
+inline Globals createGlobals(uint32_t width, uint32_t height, uint32_t meshletCount, const float *eye = nullptr,
+                             const float *centre = nullptr, const float *up = nullptr, float fovDeg = 45.0f,
+                             float zNear = 0.1f, bool flipY = true) {
+    Globals g{};
+    MCULL_CHECK(static_cast<mcull_ctx *>(nullptr),
+                mcull_create_globals(eye, centre, up, fovDeg, zNear, width, height, flipY ? 1 : 0, meshletCount, &g));
+    return g;
+}
+// The matrices Engine::updateTransforms generates (Engine.cpp:2353-2377; the reference's seed is 42).
+inline std::vector<Transform> referenceTransforms(uint32_t drawCount, uint32_t seed = 42) {
+    std::vector<Transform> t(drawCount);
+    MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_reference_transforms(drawCount, seed, t.data()));
+    return t;
+}
+// Engine::createIndirectBuffer (Engine.cpp:1466-1484): the static commands of the reference.
+inline std::vector<DrawIndirect> createIndirectBuffer(uint32_t drawCount, uint32_t meshletCount, uint32_t indexCount) {
+    std::vector<DrawIndirect> d(drawCount);
+    MCULL_CHECK(static_cast<mcull_ctx *>(nullptr), mcull_create_indirect_buffer(drawCount, meshletCount, indexCount, d.data()));
+    return d;
+}
 
 // The four arrays of Engine.hpp:215-218 and the load-time pipeline that fills them.
 class Mesh {
@@ -197,6 +223,8 @@ public:
         MCULL_CHECK(ctx_, mcull_scene_upload(ctx_, path.c_str()));
         meshletCount_ = info.meshlet_count;
     }
+    uint64_t meshletCount() const { return meshletCount_; }
+    uint64_t instanceCount() const { return instances_; }
     void waitIdle() { MCULL_CHECK(ctx_, mcull_synchronize(ctx_)); }
     mcull_ctx *handle() const { return ctx_; }
 

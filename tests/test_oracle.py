@@ -4,6 +4,7 @@ source, the committed golden fixtures, and the independent numpy restatement (or
 PARITY UNPINNED: the reference has no tests or golden vectors for this path; these pin the oracle
 against its own fixtures, a second restatement and hand-derived answers.
 """
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -439,6 +440,37 @@ def test_config1_inputs_reproduced(O, H, config1, manifest):
     d = O.create_indirect_buffer(1000, 326, 28944 * 3)
     assert d.tobytes() == H.create_indirect_buffer(1000, 326, 28944 * 3).tobytes()
     assert d["commandMeshIndirect"]["taskCount"][0] == 11 and d["commandMeshIndirect"]["firstTask"].max() == 0
+
+
+def test_library_host_inputs_equal_golden(O, mc, config1):
+    """The library's own C++ createGlobals / updateTransforms / createIndirectBuffer (host code, no
+    GPU) against the committed config-1 inputs and, for other cameras and seeds, against the oracle."""
+    g, t = config1["globals"], config1["transforms"]
+    assert mc.create_globals(800, 600, 326).tobytes() == g.tobytes()
+    assert mc.reference_transforms(1000, 42).tobytes() == t.tobytes()
+    assert mc.create_indirect_buffer(1000, 326, 28944 * 3).tobytes() == O.create_indirect_buffer(1000, 326, 28944 * 3).tobytes()
+    for eye, centre, up, fov, zn, w, h, flip in [((0, -10, 0), (0, 0, 0), (0, 0, 1), 90.0, 0.1, 64, 48, False),
+                                                 ((51.0, 54.4, 40.8), (1, 2, 3), (0, 1, 0), 33.0, 0.5, 3840, 2160, True),
+                                                 ((-3, 4, -5), (0.5, 0.25, 8), (1, 1, 0), 120.0, 0.01, 8192, 8192, True)]:
+        a = mc.create_globals(w, h, 7, eye=eye, centre=centre, up=up, fov_deg=fov, z_near=zn, flip_y=flip)
+        b = O.create_globals(eye=eye, centre=centre, up=up, fov_deg=fov, z_near=zn, width=w, height=h, flip_y=flip, meshlet_count=7)
+        assert a.tobytes() == b.tobytes()
+        a["frustum"] = 0
+        assert mc.extract_frustum(a).tobytes() == b.tobytes()
+    # the private generator leaves the process-wide rand() alone and restarts from the seed each call
+    assert mc.reference_transforms(10, 42).tobytes() == t[:10].tobytes()
+    assert mc.reference_transforms(10, 43).tobytes() != t[:10].tobytes()
+    libc = C.CDLL(None)
+    libc.srand(5)
+    first = libc.rand()
+    libc.srand(5)
+    mc.reference_transforms(3, 42)
+    assert libc.rand() == first
+    assert mc.reference_transforms(0, 42).shape == (0,)
+    # a degenerate camera (eye == centre) gives NaNs, as the reference would, not an error
+    assert np.isnan(mc.create_globals(8, 8, 0, eye=(1, 1, 1), centre=(1, 1, 1))["view"]).any()
+    with pytest.raises(mc.McullError):
+        mc.create_globals(0, 600, 1)
 
 
 def test_config1_results_match_manifest_and_numpy(O, NP, kitten, config1, manifest):

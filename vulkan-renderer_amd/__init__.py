@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_load_obj", "mcull_mesh_from_arrays", "mcull_mesh_optimize", "mcull_mesh_build_meshlets", "mcull_mesh_counts",
     "mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets", "mcull_mesh_upload",
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
+    "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
 ]
 
 
@@ -138,6 +139,10 @@ for _name in ("mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_d
 _sig("mcull_mesh_upload", _I, [_P, _P])
 _sig("mcull_mesh_save", _I, [_P, C.c_char_p])
 _sig("mcull_mesh_destroy", None, [_P])
+_sig("mcull_create_globals", _I, [_P, _P, _P, C.c_float, C.c_float, _U32, _U32, _I, _U32, _P])
+_sig("mcull_extract_frustum", _I, [_P])
+_sig("mcull_reference_transforms", _I, [_U32, _U32, _P])
+_sig("mcull_create_indirect_buffer", _I, [_U32, _U32, _U32, _P])
 
 
 class McullError(RuntimeError):
@@ -161,6 +166,45 @@ def hiz_layout(width, height):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def create_globals(width=800, height=600, meshlet_count=0, eye=None, centre=None, up=None, fov_deg=45.0, z_near=0.1,
+                   flip_y=True):
+    """Engine::createGlobals through the library's host code (Engine.cpp:2323-2352); the defaults are
+    the reference's camera and window."""
+    g = np.zeros(1, dtype=GLOBALS)
+    vecs = [None if v is None else np.ascontiguousarray(v, dtype="<f4") for v in (eye, centre, up)]
+    rc = lib.mcull_create_globals(*[None if v is None else _np_ptr(v) for v in vecs], fov_deg, z_near, width, height,
+                                  1 if flip_y else 0, meshlet_count, _np_ptr(g))
+    if rc != OK:
+        raise McullError(rc, "create_globals")
+    return g
+
+
+def extract_frustum(g):
+    """Recompute the five planes of a GLOBALS record in place from its view and proj."""
+    rc = lib.mcull_extract_frustum(_np_ptr(g))
+    if rc != OK:
+        raise McullError(rc, "extract_frustum")
+    return g
+
+
+def reference_transforms(draw_count=1000, seed=42):
+    """Engine::updateTransforms (Engine.cpp:2353-2377): srand(seed) and six rand() draws per instance."""
+    t = np.zeros(draw_count, dtype=TRANSFORM)
+    rc = lib.mcull_reference_transforms(draw_count, seed, _np_ptr(t))
+    if rc != OK:
+        raise McullError(rc, "reference_transforms")
+    return t
+
+
+def create_indirect_buffer(draw_count, meshlet_count, index_count):
+    """Engine::createIndirectBuffer (Engine.cpp:1466-1484): the reference's static commands."""
+    d = np.zeros(draw_count, dtype=DRAW_INDIRECT)
+    rc = lib.mcull_create_indirect_buffer(draw_count, meshlet_count, index_count, _np_ptr(d))
+    if rc != OK:
+        raise McullError(rc, "create_indirect_buffer")
+    return d
 
 
 def _scene_chk(rc, path):
