@@ -469,10 +469,10 @@ def run_hiz(env):
     value = w * h * env.world / (elapsed / args.steps) / 1e9
     if env.rank == 0:
         out = base_line(env, "Hi-Z pyramid pixels reduced/sec", "Gpixel/s", value, elapsed, args.steps,
-                        "Hi-Z min pyramid of a %dx%d depth image, %d levels, one launch%s"
+                        "Hi-Z min pyramid of a %dx%d depth image, %d levels%s"
                         % (w, h, levels, " (replicas: every GPU builds its own)" if env.world > 1 else ""))
-        traffic, src = pmc_summary_bytes("r01_bench_hiz", ("hiz_tile_kernel",)) if (w, h) == (8192, 8192) else (None, None)
-        out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_tile_kernel", traffic, src,
+        traffic, src = pmc_summary_bytes("r01_bench_hiz", ("hiz_rows_kernel", "hiz_tile_kernel")) if (w, h) == (8192, 8192) else (None, None)
+        out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_rows_kernel + hiz_tile_kernel", traffic, src,
                                    bytes_per_pixel=round(algo / (w * h), 3))
         if not args.no_cpu_baseline and env.world == 1:
             import oracle as O

@@ -183,16 +183,21 @@ def test_hiz_rebuild_same_buffer_sees_no_stale_texels(mc, O, ctx, shape):
                 assert x.view("<u4").tobytes() == y.view("<u4").tobytes(), "level %d differs" % k
 
 
-def test_hiz_single_launch_form(mc, O, monkeypatch):
-    """MCULL_HIZ_SINGLE_LAUNCH=1: levels >= 7 finished inside the tile launch by the last-arriving
-    waves (tickets, write-through hand-over).  Same pyramids bit for bit, also when rebuilt into the
-    same buffer with different depth."""
-    monkeypatch.setenv("MCULL_HIZ_SINGLE_LAUNCH", "1")
+@pytest.mark.parametrize("switch", ["MCULL_HIZ_SINGLE_LAUNCH", "MCULL_HIZ_STREAM", "MCULL_HIZ_TILES"])
+def test_hiz_forced_schemes(mc, O, monkeypatch, switch):
+    """The pyramid schemes the library chooses between by image size, each forced for every size:
+    MCULL_HIZ_STREAM (streaming pass for levels 0-3, then tiles on level 3 with the top levels handed
+    to the last-arriving waves by tickets), MCULL_HIZ_TILES (tiles on the depth image + a one-workgroup
+    launch), MCULL_HIZ_SINGLE_LAUNCH (tiles on the depth image, tickets).  Same pyramids bit for bit,
+    NaN / signed zero / infinities included, also when rebuilt into the same buffer."""
+    monkeypatch.setenv(switch, "1")
     c = mc.Context(0)
-    monkeypatch.delenv("MCULL_HIZ_SINGLE_LAUNCH")
+    monkeypatch.delenv(switch)
     rs = np.random.RandomState(17)
-    for h, w in ((600, 800), (65, 127), (1080, 1920), (2160, 3840), (37, 4000), (1, 300), (4096, 4096), (130, 129)):
+    for h, w in ((600, 800), (65, 127), (1080, 1920), (2160, 3840), (37, 4000), (1, 300), (4096, 4096), (130, 129),
+                 (32, 32), (33, 47), (31, 64), (768, 1366), (40, 8192), (1023, 1025), (64, 4099)):
         a = rs.uniform(0, 1, (h, w)).astype("<f4")
+        a.flat[rs.randint(0, h * w, 8)] = [np.nan, -0.0, 0.0, np.inf, -np.inf, 1e-40, np.nan, 0.5]
         for depth in (a, (1.0 - a).astype("<f4")):
             ref = O.hiz_levels(O.hiz_build(depth, threads=8), w, h)
             c.hiz_build(depth, view=1)

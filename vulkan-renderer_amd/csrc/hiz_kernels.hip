@@ -1,5 +1,7 @@
-// Hi-Z min-depth pyramid for gfx950: levels 0-6 in one pass over the depth image, the rest by a
-// second one-workgroup launch (default) or inside the same launch (single_pass).
+// Hi-Z min-depth pyramid for gfx950.  Images of at least 32x32 take two launches: a streaming pass
+// over the depth image that produces levels 0-3 from registers (hiz_rows_kernel), then the tiled
+// kernel below applied to level 3, which finishes the pyramid.  Smaller images run the tiled kernel
+// on the depth image itself (levels 0-6) and a one-workgroup launch for the rest.
 //
 // Reference: shaders/shader.comp:12-31 run once per level with a barrier in between
 // (Engine.cpp:1834-1866): level 0 copies the depth image, level k takes the 2x2 minimum of
@@ -101,7 +103,10 @@ __device__ __forceinline__ float wave_level(float v, uint32_t K, uint32_t levels
 
 // Tiled kernel.  grid = (tiles_x, tiles_y), 256 threads, thread (tx,ty) = (t&15, t>>4) owns the
 // 4x4 level-0 patch at (tile_x0 + 4*tx, tile_y0 + 4*ty).  VEC: rows are 16-byte aligned (w % 4 == 0).
-template <bool VEC, bool SINGLE_PASS>
+// COPY: the source is the depth image and is copied out as level 0; otherwise the source is a level
+// of the pyramid that is already in place (`depth` points at it, `tbl` at that level's table entries
+// and `levels` counts from it), just written by the previous launch, so it is read with plain loads.
+template <bool VEC, bool SINGLE_PASS, bool COPY>
 __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
                                                           uint32_t levels, uint32_t *__restrict__ counter) {
@@ -116,15 +121,16 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
         const uint32_t y = min(y0 + r, h - 1);
         if (VEC && x0 + 3 < w) {
             // the depth image is read once and level 0 is far larger than the caches: streaming hints
-            const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(depth + (size_t)y * w + x0));
+            const f4v *src = reinterpret_cast<const f4v *>(depth + (size_t)y * w + x0);
+            const f4v q = COPY ? __builtin_nontemporal_load(src) : *src;
             p[r][0] = q.x; p[r][1] = q.y; p[r][2] = q.z; p[r][3] = q.w;
-            if (y0 + r < h) __builtin_nontemporal_store(q, reinterpret_cast<f4v *>(pyr + (size_t)y * w + x0));
+            if (COPY && y0 + r < h) __builtin_nontemporal_store(q, reinterpret_cast<f4v *>(pyr + (size_t)y * w + x0));
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const uint32_t x = min(x0 + c, w - 1);
                 p[r][c] = depth[(size_t)y * w + x];
-                if (y0 + r < h && x0 + c < w) pyr[(size_t)y * w + x] = p[r][c];
+                if (COPY && y0 + r < h && x0 + c < w) pyr[(size_t)y * w + x] = p[r][c];
             }
         }
     }
@@ -242,39 +248,157 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     }
 }
 
+constexpr uint32_t kRowsPerWave = 8;
+constexpr uint64_t kStreamMinTexels = 6ull << 20;
+// Eight rows x 4 texels of one lane: levels 0-3 stored, the level-3 texel returned (both lanes of a pair hold it).
+template <bool VEC>
+__device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint32_t w, uint32_t h, float *__restrict__ pyr,
+                                           const uint32_t *__restrict__ tbl, uint32_t x0, uint32_t y0, uint32_t lane) {
+    // ---- level 0: copied out as read (shader.comp:19-21)
+    float p[8][4];
+    if (VEC) {
+        const bool col_in = x0 < w;
+        const uint32_t xc = min(x0, w - 4u);  // w % 4 == 0: columns past the edge re-read the last aligned group
+        f4v q[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++)
+            q[r] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(depth + (size_t)min(y0 + r, h - 1u) * w + xc));
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            if (col_in && y0 + r < h) __builtin_nontemporal_store(q[r], reinterpret_cast<f4v *>(pyr + (size_t)(y0 + r) * w + x0));
+            p[r][0] = q[r].x; p[r][1] = q[r].y; p[r][2] = q[r].z; p[r][3] = q[r].w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            const size_t row = (size_t)min(y0 + r, h - 1u) * w;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                p[r][c] = depth[row + min(x0 + c, w - 1u)];
+                if (y0 + r < h && x0 + c < w) pyr[row + x0 + c] = p[r][c];
+            }
+        }
+    }
+    // ---- level 1: 4 rows x 2 texels
+    float q1[4][2];
+    {
+        const uint32_t lw = tbl[1], lh = tbl[16 + 1];
+        float *dst = pyr + tbl[32 + 1];
+        const uint32_t bx = x0 >> 1, by = y0 >> 1;
+        const bool vec2 = ((lw | tbl[32 + 1]) & 1u) == 0u;  // rows and level base 8-byte aligned
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            q1[j][0] = min4(p[2 * j][0], p[2 * j][1], p[2 * j + 1][0], p[2 * j + 1][1]);
+            q1[j][1] = min4(p[2 * j][2], p[2 * j][3], p[2 * j + 1][2], p[2 * j + 1][3]);
+            if (by + j < lh) {
+                if (vec2 && bx + 1 < lw) {
+                    *reinterpret_cast<float2 *>(dst + (size_t)(by + j) * lw + bx) = make_float2(q1[j][0], q1[j][1]);
+                } else {
+                    if (bx < lw) dst[(size_t)(by + j) * lw + bx] = q1[j][0];
+                    if (bx + 1 < lw) dst[(size_t)(by + j) * lw + bx + 1] = q1[j][1];
+                }
+            }
+        }
+    }
+    // ---- level 2: 2 rows x 1 texel
+    float q2[2];
+    {
+        const uint32_t lw = tbl[2], lh = tbl[16 + 2];
+        float *dst = pyr + tbl[32 + 2];
+        const uint32_t bx = x0 >> 2, by = y0 >> 2;
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            q2[j] = min4(q1[2 * j][0], q1[2 * j][1], q1[2 * j + 1][0], q1[2 * j + 1][1]);
+            if (bx < lw && by + j < lh) dst[(size_t)(by + j) * lw + bx] = q2[j];
+        }
+    }
+    // ---- level 3: lanes 2i and 2i+1 hold the left and right children; both end up with the result
+    const uint32_t lw = tbl[3], lh = tbl[16 + 3];
+    const uint32_t bx = x0 >> 3, by = y0 >> 3;
+    const bool right = (lane & 1u) != 0u;
+    const float top_o = __shfl_xor(q2[0], 1), bot_o = __shfl_xor(q2[1], 1);
+    const float q3 = min4(right ? top_o : q2[0], right ? q2[0] : top_o, right ? bot_o : q2[1], right ? q2[1] : bot_o);
+    if (!right && bx < lw && by < lh) pyr[tbl[32 + 3] + (size_t)by * lw + bx] = q3;
+    return q3;
+}
+
+// Streaming pass: levels 0-3 from one read of the depth image, no LDS and no barrier.  Every wave is
+// on its own: lane l owns the 4 texels [4l, 4l+4) of 8 consecutive rows, so each load and store
+// instruction of a wave covers one contiguous kilobyte of a row (the 64x64 tiles above touch four
+// 256-byte pieces instead, which costs 13 % of the copy bandwidth on a large image).  Levels 1 and 2
+// reduce inside the thread, level 3 joins two neighbouring lanes with a quad shuffle.  A workgroup is
+// four such waves stacked vertically (256 x 32 texels).  Requires w, h >= 16, so that no level up to
+// 3 has collapsed and every stored texel's children lie inside their level (rows and columns beyond
+// the image are read clamped and never stored).  (Sixteen rows per wave with level 4 from a second
+// shuffle measured slower on large images, in one piece - 114 registers - or as two halves.)
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void hiz_rows_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
+                                                          float *__restrict__ pyr, const uint32_t *__restrict__ tbl) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t x0 = blockIdx.x * 256u + 4u * lane;
+    const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (y0 >= h) return;  // the whole wave lies below the image
+    hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane);
+}
+
+template <bool COPY>
+static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
+                               const uint32_t *level_table, uint32_t *counter, bool single_pass, hipStream_t st) {
+    const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
+    const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(src) & 15u) == 0u &&
+                     (!COPY || (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u);
+    if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
+        if (vec)
+            hipLaunchKernelGGL((hiz_tile_kernel<true, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
+                               level_table, levels, counter);
+        else
+            hipLaunchKernelGGL((hiz_tile_kernel<false, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
+                               level_table, levels, counter);
+        return hipGetLastError();
+    }
+    if (vec)
+        hipLaunchKernelGGL((hiz_tile_kernel<true, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
+                           level_table, levels, counter);
+    else
+        hipLaunchKernelGGL((hiz_tile_kernel<false, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
+                           level_table, levels, counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (levels > 7) {
+        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, src, w, h, pyramid, level_table, levels, 7u);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+// `mode`: 0 = by size: the streaming pass + tiles on level 3 (tickets hand the top levels over inside
+// that launch) from kStreamMinTexels on, below that the tiles on the depth image + a one-workgroup
+// launch for levels >= 7 (measured cross-over: 2560x1440 14.6 us against 15.4 us streamed, 3840x2160
+// 25.0 us against 22.9 us); 1 = always the latter; 2 = tiles on the depth image with the top levels
+// inside the same launch; 3 = always the streaming pass.
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, bool single_pass, hipStream_t st) {
+                      const uint32_t *level_table, uint32_t *counter, int mode, hipStream_t st) {
     if (w < 4 || h < 4) {
         hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, levels,
                            0u);
         return hipGetLastError();
     }
-    const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
+    // level 3 must itself be at least 4x4, the tiled kernel's own precondition
+    const bool stream = mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels);
+    if (!stream || w < 32 || h < 32)
+        return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, st);
+    constexpr uint32_t base = 3;  // the last level the streaming pass writes
+    const dim3 grid((w + 255u) / 256u, (h + 4u * kRowsPerWave - 1u) / (4u * kRowsPerWave));
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
                      (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u;
-    if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
-        if (vec)
-            hipLaunchKernelGGL((hiz_tile_kernel<true, true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
-                               level_table, levels, counter);
-        else
-            hipLaunchKernelGGL((hiz_tile_kernel<false, true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
-                               level_table, levels, counter);
-        return hipGetLastError();
-    }
-    if (vec)
-        hipLaunchKernelGGL((hiz_tile_kernel<true, false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
-                           level_table, levels, counter);
-    else
-        hipLaunchKernelGGL((hiz_tile_kernel<false, false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid,
-                           level_table, levels, counter);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (levels > 7) {
-        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, levels,
-                           7u);
-        e = hipGetLastError();
-    }
-    return e;
+    if (vec) hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table);
+    else hipLaunchKernelGGL((hiz_rows_kernel<false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess || levels <= base + 1u) return e;
+    // the tiled kernel with the last level written above as its source: the table pointer and the level count shift
+    size_t off = 0;
+    for (uint32_t i = 0; i < base; i++) off += (size_t)max(1u, w >> i) * max(1u, h >> i);
+    return launch_tiles<false>(pyramid + off, w >> base, h >> base, pyramid, levels - base, level_table + base, counter, true, st);
 }
 
 }  // namespace mcull

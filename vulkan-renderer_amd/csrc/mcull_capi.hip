@@ -53,7 +53,7 @@ struct mcull_ctx {
     DevBuf depth_staging, hiz_counter;
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
     uint32_t depth_w = 0, depth_h = 0;
-    bool hiz_single_pass = false;  // levels >= 7 finished inside the tile launch instead of by a second small launch
+    int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
 
     // cull scratch + outputs, one set per view slot: mcull_cull uses slot 0, mcull_cull_views slot i
     // for its i-th view; `cur` is the slot the download / rebase / payload / rasterise calls refer to
@@ -234,8 +234,10 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     // Finishing levels >= 7 with a second one-workgroup launch measured faster than or equal to the
     // in-launch hand-over at every size from 800x600 to 8192^2, so it is the default; the single-launch
     // form stays selectable for callers that want one dispatch.
+    // evaluation switches for the alternative pyramid schemes (results are identical)
+    const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
-    c->hiz_single_pass = single && single[0] == '1';
+    c->hiz_mode = (single && single[0] == '1') ? 2 : (tiles && tiles[0] == '1') ? 1 : (streamed && streamed[0] == '1') ? 3 : 0;
     *out = c;
     return MCULL_OK;
 }
@@ -494,7 +496,7 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
     s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
-                                (uint32_t *)c->hiz_counter.p, c->hiz_single_pass, c->stream));
+                                (uint32_t *)c->hiz_counter.p, c->hiz_mode, c->stream));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;

@@ -92,7 +92,7 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero)
 constexpr size_t kHizCounterBytes = 2048;
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, bool single_pass, hipStream_t st);
+                      const uint32_t *level_table, uint32_t *counter, int mode, hipStream_t st);
 
 
 }  // namespace mcull
