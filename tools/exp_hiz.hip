@@ -1,4 +1,7 @@
-// Throwaway experiment: where does the tile kernel lose time against a plain copy?
+// Design-evidence benchmark (not part of the product): where the 64x64-tile pyramid kernel loses time
+// against a plain copy - access pattern (tile-shaped against row-shaped waves, level 0 alone and levels
+// 0-2) and the two stages of the streaming scheme timed separately.  Build + run:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 tools/exp_hiz.hip -o tools/exp_hiz
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
