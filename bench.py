@@ -130,11 +130,20 @@ class Env:
             # K timed steps measure sustained throughput whatever W and K are.
             t_ramp = time.perf_counter()
             k = 0
-            while (time.perf_counter() - t_ramp) * 1e3 < self.args.ramp_ms:
+            while True:
                 for _ in range(8):
                     step(k)
                     k += 1
                 torch.cuda.synchronize()
+                done = (time.perf_counter() - t_ramp) * 1e3 >= self.args.ramp_ms
+                if self.multi:
+                    # every step issues a collective, so all ranks must run the same number of ramp
+                    # steps: they stop together, once the slowest rank has had its ramp time
+                    flag = torch.tensor([1 if done else 0], device=self.device, dtype=torch.int32)
+                    self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+                    done = bool(flag.item())
+                if done:
+                    break
         for k in range(warmup):
             step(k)
         self.fence()
