@@ -88,6 +88,11 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
             raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
+        if args.rehearse_shared_gpu:
+            # control-flow rehearsal of the multi-rank step on a one-GPU box: every rank uses GPU 0 and the
+            # collectives run over gloo on host copies (RCCL refuses two ranks on one device); its numbers
+            # mean nothing
+            self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
         self.multi = self.world > 1 or args.force_dist
@@ -97,7 +102,22 @@ class Env:
 
             if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-            dist.init_process_group("nccl", device_id=self.device)
+            # RCCL prints a version banner on stdout when its communicator comes up; stdout carries the
+            # one JSON line only, so the banner is sent to stderr (communicator creation forced here).
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if args.rehearse_shared_gpu:
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.device)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
             self.dist = dist
         self.mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
         self.host = importlib.import_module("vulkan-renderer_amd.host")
@@ -325,7 +345,7 @@ def run_cull(env, workload):
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_cull[b])
 
-                gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b])
+                gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b].cpu() if args.rehearse_shared_gpu else cmds_packed[b])
                 if gather_lists:
                     env.mdist.gather_visible_lists(lst, gathered[b][0])
                 ev_comm[b].record(comm)
@@ -758,6 +778,8 @@ def main():
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="control-flow rehearsal only: all ranks share GPU 0, collectives over gloo on host copies")
     args = ap.parse_args()
     env = Env(args)
     if args.workload == "hiz":
