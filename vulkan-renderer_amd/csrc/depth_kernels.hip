@@ -18,17 +18,20 @@
 // t + 64.  Triangles whose pixel box exceeds kSmallBox pixels are rasterised by the whole wave, one
 // after another, so a single lane never walks a large box alone.  Depth is stored as the float's
 // bit pattern and merged with atomicMax (non-negative floats order like unsigned integers).
+#include <cstdlib>
+
 #include "mcull_internal.h"
 
 namespace mcull {
 
 constexpr int kRasterBlock = 256;
-constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own
+constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own (default)
 
 struct RasterConst {
     float vp[16];  // proj * view, column-major
     float wf, hf;
     uint32_t w, h;
+    uint32_t small_box;
 };
 
 struct Tri {
@@ -110,21 +113,32 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
         return Hdr{m->dataOffset, m->vertexCount, m->triangleCount};
     };
     auto load_vertex_id = [&](const Hdr &hd) { return lane < hd.vc ? meshlet_data[hd.off + lane] : 0u; };
+    // the three local vertex ids of triangle t, packed into one word (0 for t beyond the meshlet's triangles)
+    auto load_corners = [&](const Hdr &hd, uint32_t t) {
+        if (t >= hd.tc) return 0u;
+        const uint8_t *l = reinterpret_cast<const uint8_t *>(meshlet_data + hd.off + hd.vc) + 3u * t;
+        return (uint32_t)l[0] | ((uint32_t)l[1] << 8) | ((uint32_t)l[2] << 16);
+    };
     // Software pipeline over the dependent loads entry -> header -> vertex id -> vertex: the entry is
     // fetched three iterations ahead, the header two, the vertex id one, so that an iteration waits
-    // for a single memory round trip (the vertex itself) instead of four.
+    // for a single memory round trip (the vertex itself) instead of four.  The corner indices of the
+    // triangles (two per lane: a meshlet has at most 124 <= 128) travel with the vertex id.  (One stage
+    // more - position and matrix one iteration ahead - costs 17 registers, drops a wave per SIMD and
+    // measured 7 % slower.)
     mcull_visible ent_a = load_entry(wave0), ent_b = load_entry(wave0 + n_waves), ent_c = load_entry(wave0 + 2 * n_waves);
     Hdr hdr_a = load_header(ent_a), hdr_b = load_header(ent_b);
     uint32_t gid_a = load_vertex_id(hdr_a);
+    uint32_t cor0_a = load_corners(hdr_a, lane), cor1_a = load_corners(hdr_a, lane + 64u);
     for (uint64_t e = wave0; e < n; e += n_waves) {
         const mcull_visible ent_d = load_entry(e + 3 * n_waves);
         const Hdr hdr_c = load_header(ent_c);
         const uint32_t gid_b = load_vertex_id(hdr_b);
+        const uint32_t cor0_b = load_corners(hdr_b, lane), cor1_b = load_corners(hdr_b, lane + 64u);
         const mcull_visible ent = ent_a;
-        const uint32_t off = hdr_a.off, vc = hdr_a.vc, tc = hdr_a.tc, gid = gid_a;
+        const uint32_t vc = hdr_a.vc, tc = hdr_a.tc, gid = gid_a, cor0 = cor0_a, cor1 = cor1_a;
         ent_a = ent_b; ent_b = ent_c; ent_c = ent_d;
         hdr_a = hdr_b; hdr_b = hdr_c;
-        gid_a = gid_b;
+        gid_a = gid_b; cor0_a = cor0_b; cor1_a = cor1_b;
         // mvp = (proj*view) * model, the element sum in the order k = 0..3: lane i < 16 evaluates element
         // i = 4*c + r, and the sixteen results are broadcast into SGPRs
         float mvp[16];
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
         // lane l: local vertex l -> clip and screen position
         ClipV cv = {0.0f, 0.0f, 0.0f, 0.0f};
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        int ok = 0, inside = 0;
+        int flags = 0;  // bit 0: w > 0 (projectable), bit 1: in front of the near plane
         if (lane < vc) {
             const mcull_vertex *v = vertices + gid;
             const float px = v->vx, py = v->vy, pz = v->vz;
@@ -151,20 +165,21 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
             cv.z = ((mvp[2] * px + mvp[6] * py) + mvp[10] * pz) + mvp[14];
             cv.w = ((mvp[3] * px + mvp[7] * py) + mvp[11] * pz) + mvp[15];
             const ScreenV sv = to_screen(cv, rc.wf, rc.hf);
-            sx = sv.x; sy = sv.y; sz = sv.z; ok = sv.ok;
-            inside = (cv.w - cv.z) >= 0.0f;  // in front of the near plane
+            sx = sv.x; sy = sv.y; sz = sv.z;
+            flags = sv.ok | (((cv.w - cv.z) >= 0.0f) ? 2 : 0);
         }
-        const uint8_t *locals = reinterpret_cast<const uint8_t *>(meshlet_data + off + vc);
-        for (uint32_t base = 0; base < tc; base += 64u) {  // wave-uniform trip count
+        for (uint32_t base = 0; base < tc; base += 64u) {  // wave-uniform trip count (at most 2: the record's u8 holds <= 124)
             const uint32_t t = base + lane;
             const bool valid = t < tc;
-            const uint32_t i0 = valid ? locals[3 * t] : 0u, i1 = valid ? locals[3 * t + 1] : 0u, i2 = valid ? locals[3 * t + 2] : 0u;
+            const uint32_t cor = base == 0u ? cor0 : cor1;
+            const uint32_t i0 = cor & 0xffu, i1 = (cor >> 8) & 0xffu, i2 = cor >> 16;
             Tri tr;
             tr.x0 = __shfl(sx, (int)i0); tr.y0 = __shfl(sy, (int)i0); tr.z0 = __shfl(sz, (int)i0);
             tr.x1 = __shfl(sx, (int)i1); tr.y1 = __shfl(sy, (int)i1); tr.z1 = __shfl(sz, (int)i1);
             tr.x2 = __shfl(sx, (int)i2); tr.y2 = __shfl(sy, (int)i2); tr.z2 = __shfl(sz, (int)i2);
-            int tri_ok = __shfl(ok, (int)i0) & __shfl(ok, (int)i1) & __shfl(ok, (int)i2);
-            const int in0 = __shfl(inside, (int)i0), in1 = __shfl(inside, (int)i1), in2 = __shfl(inside, (int)i2);
+            const int f0 = __shfl(flags, (int)i0), f1 = __shfl(flags, (int)i1), f2 = __shfl(flags, (int)i2);
+            int tri_ok = f0 & f1 & f2 & 1;
+            const int in0 = f0 >> 1, in1 = f1 >> 1, in2 = f2 >> 1;
             const int n_in = in0 + in1 + in2;
             // n_in == 3: the triangle as it is; 0: nothing; 1 or 2: clipped to a triangle or a quad (= two
             // triangles fanned from the polygon's first vertex, polygon order as the edge walk 0->1->2->0 emits it)
@@ -201,10 +216,8 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
                 }
             }
             const bool first = valid && (n_in == 3 || needs_clip);
-            const int rounds = __any(second) ? 2 : 1;  // wave-uniform
-            for (int round = 0; round < rounds; round++) {
-                const Tri cur = round == 0 ? tr : tr2;
-                const bool cur_valid = round == 0 ? (first && tri_ok) : (second && tri2_ok);
+            // rasterise one triangle per lane (wave-wide call: the large boxes use shuffles)
+            auto raster_round = [&](const Tri &cur, bool cur_valid) {
                 const float area = (cur.x1 - cur.x0) * (cur.y2 - cur.y0) - (cur.x2 - cur.x0) * (cur.y1 - cur.y0);
                 bool draw = cur_valid && (area < 0.0f);  // front-facing, in front of the eye, not NaN
                 const float minx = fminf(fminf(cur.x0, cur.x1), cur.x2), maxx = fmaxf(fmaxf(cur.x0, cur.x1), cur.x2);
@@ -212,19 +225,21 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
                 const float x_lo = fmaxf(ceilf(minx - 0.5f), 0.0f), x_hi = fminf(floorf(maxx - 0.5f), (float)(rc.w - 1u));
                 const float y_lo = fmaxf(ceilf(miny - 0.5f), 0.0f), y_hi = fminf(floorf(maxy - 0.5f), (float)(rc.h - 1u));
                 draw = draw && (x_lo <= x_hi) && (y_lo <= y_hi);
+                if (!__any(draw)) return;  // wave-uniform: nothing in this round covers a pixel centre
                 uint32_t bx = 0, by = 0, bw = 0, bh = 0;
                 if (draw) {
                     bx = (uint32_t)x_lo; by = (uint32_t)y_lo;
                     bw = (uint32_t)x_hi - bx + 1u; bh = (uint32_t)y_hi - by + 1u;
                 }
-                const bool tl0 = edge_top_left(cur.x1, cur.y1, cur.x2, cur.y2), tl1 = edge_top_left(cur.x2, cur.y2, cur.x0, cur.y0),
-                           tl2 = edge_top_left(cur.x0, cur.y0, cur.x1, cur.y1);
                 const uint64_t box = (uint64_t)bw * bh;
-                const bool small = draw && box <= kSmallBox;
+                const bool small = draw && box <= rc.small_box;
                 if (small) {
+                    const bool tl0 = edge_top_left(cur.x1, cur.y1, cur.x2, cur.y2), tl1 = edge_top_left(cur.x2, cur.y2, cur.x0, cur.y0),
+                               tl2 = edge_top_left(cur.x0, cur.y0, cur.x1, cur.y1);
+                    uint32_t xx = 0, yy = 0;  // row-major walk of the box without a division per pixel
                     for (uint32_t p = 0; p < (uint32_t)box; p++) {
-                        const uint32_t yy = p / bw, xx = p - yy * bw;
                         raster_pixel(cur, area, tl0, tl1, tl2, bx + xx, by + yy, rc.w, depth_bits);
+                        if (++xx == bw) { xx = 0; ++yy; }
                     }
                 }
                 // large boxes: the whole wave walks one triangle at a time
@@ -240,13 +255,14 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
                     const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
                     const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
                                t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
-                    const uint64_t cells = (uint64_t)ow * oh;
-                    for (uint64_t p = lane; p < cells; p += 64u) {
-                        const uint32_t yy = (uint32_t)(p / ow), xx = (uint32_t)(p - (uint64_t)yy * ow);
-                        raster_pixel(b, b_area, t0, t1, t2, ox + xx, oy + yy, rc.w, depth_bits);
-                    }
+                    // the wave covers the box in 8x8-pixel tiles, lane = (lane & 7, lane >> 3) inside the tile
+                    for (uint32_t ty = lane >> 3; ty < oh; ty += 8u)
+                        for (uint32_t tx = lane & 7u; tx < ow; tx += 8u)
+                            raster_pixel(b, b_area, t0, t1, t2, ox + tx, oy + ty, rc.w, depth_bits);
                 }
-            }
+            };
+            raster_round(tr, first && tri_ok);
+            if (__any(second)) raster_round(tr2, second && tri2_ok);  // wave-uniform: the second halves of clipped quads
         }
     }
 }
@@ -259,8 +275,23 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
     for (int i = 0; i < 16; i++) rc.vp[i] = vp[i];
     rc.w = w; rc.h = h;
     rc.wf = (float)w; rc.hf = (float)h;
-    // the entry count lives on the device: a fixed grid whose waves stride over the list
-    const uint32_t grid = 256 * 8;
+    static const uint32_t small_box = [] {
+        const char *e = std::getenv("MCULL_RASTER_SMALL_BOX");  // evaluation switch; any value gives the same image
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kSmallBox;
+    }();
+    rc.small_box = small_box;
+    // The entry count lives on the device: a fixed grid whose waves stride over the list.  The grid is
+    // exactly what the device holds at once (a larger one would run as a full batch followed by a
+    // partial one, each wave of either doing the same share of the list).
+    static const uint32_t grid = [] {
+        int dev = 0, cus = 256, per_cu = 4;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel, kRasterBlock, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        const char *e = std::getenv("MCULL_RASTER_GRID");  // evaluation switch
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)(cus * per_cu);
+    }();
     hipLaunchKernelGGL(depth_raster_kernel, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
                        capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth));
     return hipGetLastError();
