@@ -1,8 +1,9 @@
 """ctypes binding of the CPU oracle (oracle/libmcull_oracle.so).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, the smoke check and the bench's cpu_baseline
-leg; the product package never imports this module.  PARITY UNPINNED: the reference has no
-tests or golden vectors for the culling path (see mcull_oracle.h).
+leg; the product package never imports this module.  PARITY PINNED ONLY IN PART: the reference
+has no tests or golden vectors for the culling path; its two screenshots pin the scene inputs and
+the load-time pipeline, the rest is PARITY UNPINNED (see mcull_oracle.h).
 """
 import ctypes as C
 import os

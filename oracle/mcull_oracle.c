@@ -1,7 +1,9 @@
 /*
  * mcull_oracle.c — CPU restatement of the reference's culling path.  TEST INFRASTRUCTURE
- * ONLY (see mcull_oracle.h).  PARITY UNPINNED: the reference holds no tests or golden
- * vectors for this path and cannot be built or run here.
+ * ONLY (see mcull_oracle.h).  PARITY PINNED ONLY IN PART: the reference holds no tests or
+ * golden vectors for this path and cannot be built or run here; its two screenshots pin the
+ * scene inputs, the load-time pipeline and the conservative side of the frustum and cone
+ * tests, everything else is PARITY UNPINNED (see the header).
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared (see oracle/Makefile).  The
  * -ffp-contract=off flag is part of the definition: no multiply-add may be fused.

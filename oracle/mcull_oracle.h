@@ -5,12 +5,19 @@
  * cpu_baseline leg do, and there only as the checker / the CPU number reported beside
  * the GPU one.
  *
- * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures for this path,
+ * PARITY PINNED ONLY IN PART: the reference has no tests or golden vectors for this path,
  * its GLSL cannot be compiled here (no glslc / Vulkan device) and Engine.cpp cannot be
  * built (glm, Vulkan, GLFW, stb and tinyobjloader headers are absent; the submodule
- * directories are empty).  This restatement is therefore anchored on the reference's
- * source text alone, cross-checked by an independent numpy restatement
- * (oracle/np_oracle.py) and by hand-derived known-answer cases (tests/).
+ * directories are empty).  The one output of the reference that exists is a pair of
+ * screenshots of its window; tests/test_reference_images.py renders the same scene through
+ * this restatement and compares.  That pins createGlobals, updateTransforms, the OBJ
+ * loader, the reorderer, the meshlet builder (partition and numbering) and the projection
+ * conventions, and shows that the frustum and cone predicates remove nothing the
+ * reference draws.  PARITY UNPINNED for everything an image cannot show: the bit-level
+ * values of the predicates and their margins, the occlusion test, the pyramid, the bounds
+ * and cones.  Those are anchored on the reference's source text alone, cross-checked by an
+ * independent numpy restatement (oracle/np_oracle.py) and by hand-derived known-answer
+ * cases (tests/).
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * reference checkout).  Where GLSL / glm leave precision implementation-defined the

@@ -1,7 +1,8 @@
 """Independent numpy (float32) restatement of the culling path, used ONLY to cross-check the C
 oracle (oracle/mcull_oracle.c): written from the reference's shader text and Engine.cpp separately,
 vectorised over meshlets instead of scalar loops, so that a slip in one restatement shows up as a
-disagreement.  TEST INFRASTRUCTURE; PARITY UNPINNED (the reference holds no golden vectors).
+disagreement.  TEST INFRASTRUCTURE; PARITY UNPINNED for what this file restates (the reference
+holds no golden vectors for predicates, pyramid or bounds).
 
 numpy float32 arithmetic is IEEE binary32 with one rounding per operation (no fused multiply-add),
 which is the arithmetic the oracle and the kernels are defined in.

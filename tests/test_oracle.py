@@ -1,8 +1,9 @@
 """CPU tests of the oracle itself (no GPU): known-answer cases derived by hand from the reference's
 source, the committed golden fixtures, and the independent numpy restatement (oracle/np_oracle.py).
 
-PARITY UNPINNED: the reference has no tests or golden vectors for this path; these pin the oracle
-against its own fixtures, a second restatement and hand-derived answers.
+PARITY UNPINNED here: the reference has no tests or golden vectors for this path; these pin the
+oracle against its own fixtures, a second restatement and hand-derived answers.  (What the
+reference's screenshots can pin is in tests/test_reference_images.py.)
 """
 import ctypes as C
 import os
