@@ -195,7 +195,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(tc, 0, 1 << 20));
     printf("-- cull pass (mask only): group assignment, streaming hint, requests in flight\n");
 #define PRODUCT(NG, NT) timeit("product cull_mask_kernel<3," #NG "," #NT ">", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, NG, NT>), dim3((n_groups + 4 * NG - 1) / (4 * NG)), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u); });
-    PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(4, false) PRODUCT(4, true)
+    PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(4, false) PRODUCT(4, true) PRODUCT(8, true)
     {
         std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
         uint64_t vis = 0; for (auto w : hm) vis += __builtin_popcountll(w);
