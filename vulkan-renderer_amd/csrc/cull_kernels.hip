@@ -480,7 +480,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 }
 
 // ------------------------------------------------------------------------------------------------
-// Scenes with more than kSuperTiles * 64 tiles: sum of each run of kSuperTiles tile counters, so
+// Scenes with more than kSuperTiles * 4 tiles: sum of each run of kSuperTiles tile counters, so
 // that the scatter pass reads at most n_tiles/256 + 255 counters per workgroup instead of n_tiles.
 __global__ __launch_bounds__(kBlock) void super_sum_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
                                                            uint32_t *__restrict__ super_counts) {
@@ -773,7 +773,8 @@ uint32_t tile_count_for(uint64_t n_groups) { return (uint32_t)((n_groups + kTile
     }
 
 uint32_t super_count_for(uint64_t n_groups) { return (tile_count_for(n_groups) + kSuperTiles - 1) / kSuperTiles; }
-bool needs_super_counts(uint64_t n_groups) { return tile_count_for(n_groups) > kSuperTiles * 64u; }
+// from 1024 tiles on (16.8 M pairs) the second level pays for its launch: 100 M pairs 0.571 ms against 0.574 ms
+bool needs_super_counts(uint64_t n_groups) { return tile_count_for(n_groups) > kSuperTiles * 4u; }
 
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
@@ -823,7 +824,7 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
     return hipGetLastError();
 }
 
-// super_counts may be nullptr (scenes up to kSuperTiles*16 tiles)
+// super_counts may be nullptr (scenes up to kSuperTiles * 4 tiles)
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st) {
