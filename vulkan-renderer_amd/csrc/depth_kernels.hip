@@ -25,7 +25,7 @@
 namespace mcull {
 
 constexpr int kRasterBlock = 256;
-constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own (default)
+constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own (2 to 32 measured the same on sub-pixel triangles)
 
 struct RasterConst {
     float vp[16];  // proj * view, column-major
@@ -275,11 +275,7 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
     for (int i = 0; i < 16; i++) rc.vp[i] = vp[i];
     rc.w = w; rc.h = h;
     rc.wf = (float)w; rc.hf = (float)h;
-    static const uint32_t small_box = [] {
-        const char *e = std::getenv("MCULL_RASTER_SMALL_BOX");  // evaluation switch; any value gives the same image
-        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kSmallBox;
-    }();
-    rc.small_box = small_box;
+    rc.small_box = kSmallBox;
     // The entry count lives on the device: a fixed grid whose waves stride over the list.  The grid is
     // exactly what the device holds at once (a larger one would run as a full batch followed by a
     // partial one, each wave of either doing the same share of the list).
@@ -289,7 +285,7 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel, kRasterBlock, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
-        const char *e = std::getenv("MCULL_RASTER_GRID");  // evaluation switch
+        const char *e = std::getenv("MCULL_RASTER_GRID");  // evaluation switch: workgroups in the grid (the image does not depend on it)
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)(cus * per_cu);
     }();
     hipLaunchKernelGGL(depth_raster_kernel, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
