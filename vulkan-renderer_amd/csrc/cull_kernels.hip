@@ -70,16 +70,24 @@ __device__ __forceinline__ float xform_scale(float4 c0) { return sqrtf(dot3(c0.x
 // Otherwise (bounds cache-resident, the pass is arithmetic-bound): the occlusion test runs first,
 // because it empties whole waves, which then skip the cone arithmetic (1 M instances of one
 // mesh: 68 ms against 88 ms with the cone test first).
-template <bool CONE_FIRST>
+// normalize(mat3(model) * cone.xyz) (shader.task:95): independent of the view
+__device__ __forceinline__ float4 world_axis(const Xform &m, float4 a) {
+    float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
+    float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
+    float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
+    const float ia = 1.0f / sqrtf(dot3(ax, ay, az, ax, ay, az));
+    return make_float4(ax * ia, ay * ia, az * ia, a.w);
+}
+
+// AXIS_READY: `a` already holds the world-space unit axis (world_axis), as when several views test the
+// same pair; otherwise it is the meshlet's local axis and is transformed only if the cone test runs.
+template <bool CONE_FIRST, bool AXIS_READY = false>
 __device__ __forceinline__ bool cone_and_occlusion(const uint32_t TESTS, const ViewConst &v, const Xform &m, float wx, float wy,
                                                    float wz, float r, float4 a, bool culled) {
     auto cone_test = [&]() {
         if ((TESTS & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
-            float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
-            float ay = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
-            float az = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
-            const float ia = 1.0f / sqrtf(dot3(ax, ay, az, ax, ay, az));
-            ax *= ia; ay *= ia; az *= ia;
+            const float4 wa = AXIS_READY ? a : world_axis(m, a);
+            const float ax = wa.x, ay = wa.y, az = wa.z;
             float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
             const float iv = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
             vx *= iv; vy *= iv; vz *= iv;
@@ -130,6 +138,26 @@ __device__ __forceinline__ bool pair_visible_impl(const uint32_t TESTS, const Vi
     return !cone_and_occlusion<CONE_FIRST>(TESTS, v, m, wx, wy, wz, r, a, culled);
 }
 
+// One pair against one of several views: world-space centre {wx, wy, wz, r} and unit axis {ax, ay, az, coneW}
+// were evaluated once for all views.
+template <bool CONE_FIRST>
+__device__ __forceinline__ bool pair_visible_prepared(const uint32_t TESTS, const ViewConst &v, const Xform &m, float4 w, float4 wa) {
+    bool culled = false;
+    if (TESTS & MCULL_TEST_FRUSTUM) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const float d = (dot3(v.frustum[i][0], v.frustum[i][1], v.frustum[i][2], w.x, w.y, w.z) + v.frustum[i][3]) + w.w;
+            culled |= d < 0.0f;
+        }
+    }
+    return !cone_and_occlusion<CONE_FIRST, true>(TESTS, v, m, w.x, w.y, w.z, w.w, wa, culled);
+}
+
+__device__ __forceinline__ float4 world_centre(const Xform &m, float scale, float4 c) {
+    return make_float4(((m.c0.x * c.x + m.c1.x * c.y) + m.c2.x * c.z) + m.c3.x, ((m.c0.y * c.x + m.c1.y * c.y) + m.c2.y * c.z) + m.c3.y,
+                       ((m.c0.z * c.x + m.c1.z * c.y) + m.c2.z * c.z) + m.c3.z, c.w * scale);
+}
+
 // The same tests for two pairs at once, written on two-element vectors: on gfx950 the compiler emits
 // the packed binary32 instructions (v_pk_mul_f32 / v_pk_add_f32: two independent IEEE operations per
 // instruction, each rounded exactly like the scalar form), which halves the multiply/add count of a
@@ -146,17 +174,41 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v dot3v(f2v ax, f2v ay, f2v az, f2v bx, f2v by, f2v bz) { return (ax * bx + ay * by) + az * bz; }
 __device__ __forceinline__ f2v splat(float x) { return f2v{x, x}; }
 
-template <bool CONE_FIRST>
-__device__ __forceinline__ void pair_visible2_impl(const uint32_t TESTS, const ViewConst &v, const Xform &m0, const Xform &m1,
-                                                   float scale0, float scale1, float4 a0, float4 a1, float4 c0, float4 c1,
-                                                   bool in0, bool in1, bool &vis0, bool &vis1) {
+struct Centre2 {
+    f2v wx, wy, wz, r;
+};
+struct Axis2 {
+    f2v x, y, z;
+};
 #define MCULL_M2(col, comp) (f2v{m0.col.comp, m1.col.comp})
+__device__ __forceinline__ Centre2 world_centre2(const Xform &m0, const Xform &m1, float scale0, float scale1, float4 c0, float4 c1) {
     const f2v cx = {c0.x, c1.x}, cy = {c0.y, c1.y}, cz = {c0.z, c1.z};
-    const f2v wx = ((MCULL_M2(c0, x) * cx + MCULL_M2(c1, x) * cy) + MCULL_M2(c2, x) * cz) + MCULL_M2(c3, x);
-    const f2v wy = ((MCULL_M2(c0, y) * cx + MCULL_M2(c1, y) * cy) + MCULL_M2(c2, y) * cz) + MCULL_M2(c3, y);
-    const f2v wz = ((MCULL_M2(c0, z) * cx + MCULL_M2(c1, z) * cy) + MCULL_M2(c2, z) * cz) + MCULL_M2(c3, z);
-    const f2v r = f2v{c0.w, c1.w} * f2v{scale0, scale1};
+    Centre2 w;
+    w.wx = ((MCULL_M2(c0, x) * cx + MCULL_M2(c1, x) * cy) + MCULL_M2(c2, x) * cz) + MCULL_M2(c3, x);
+    w.wy = ((MCULL_M2(c0, y) * cx + MCULL_M2(c1, y) * cy) + MCULL_M2(c2, y) * cz) + MCULL_M2(c3, y);
+    w.wz = ((MCULL_M2(c0, z) * cx + MCULL_M2(c1, z) * cy) + MCULL_M2(c2, z) * cz) + MCULL_M2(c3, z);
+    w.r = f2v{c0.w, c1.w} * f2v{scale0, scale1};
+    return w;
+}
+__device__ __forceinline__ Axis2 world_axis2(const Xform &m0, const Xform &m1, float4 a0, float4 a1) {
+    const f2v Ax = {a0.x, a1.x}, Ay = {a0.y, a1.y}, Az = {a0.z, a1.z};
+    Axis2 n;
+    n.x = (MCULL_M2(c0, x) * Ax + MCULL_M2(c1, x) * Ay) + MCULL_M2(c2, x) * Az;
+    n.y = (MCULL_M2(c0, y) * Ax + MCULL_M2(c1, y) * Ay) + MCULL_M2(c2, y) * Az;
+    n.z = (MCULL_M2(c0, z) * Ax + MCULL_M2(c1, z) * Ay) + MCULL_M2(c2, z) * Az;
+    const f2v la = dot3v(n.x, n.y, n.z, n.x, n.y, n.z);
+    const f2v ia = {1.0f / sqrtf(la.x), 1.0f / sqrtf(la.y)};
+    n.x *= ia; n.y *= ia; n.z *= ia;
+    return n;
+}
+#undef MCULL_M2
 
+// AXIS_READY: `axis` holds the unit world-space axes (world_axis2), evaluated once for several views;
+// otherwise they are evaluated here, and only if the cone test runs.
+template <bool CONE_FIRST, bool AXIS_READY>
+__device__ __forceinline__ void tests2(const uint32_t TESTS, const ViewConst &v, const Xform &m0, const Xform &m1, const Centre2 &w,
+                                       const Axis2 &axis, float4 a0, float4 a1, bool in0, bool in1, bool &vis0, bool &vis1) {
+    const f2v wx = w.wx, wy = w.wy, wz = w.wz, r = w.r;
     bool k0 = !in0, k1 = !in1;  // culled (a pair that does not exist counts as culled from the start)
     if (TESTS & MCULL_TEST_FRUSTUM) {
 #pragma unroll
@@ -169,18 +221,12 @@ __device__ __forceinline__ void pair_visible2_impl(const uint32_t TESTS, const V
     }
     auto cone_test = [&]() {
         if ((TESTS & MCULL_TEST_CONE) && !(k0 && k1)) {
-            const f2v Ax = {a0.x, a1.x}, Ay = {a0.y, a1.y}, Az = {a0.z, a1.z};
-            f2v ax = (MCULL_M2(c0, x) * Ax + MCULL_M2(c1, x) * Ay) + MCULL_M2(c2, x) * Az;
-            f2v ay = (MCULL_M2(c0, y) * Ax + MCULL_M2(c1, y) * Ay) + MCULL_M2(c2, y) * Az;
-            f2v az = (MCULL_M2(c0, z) * Ax + MCULL_M2(c1, z) * Ay) + MCULL_M2(c2, z) * Az;
-            const f2v la = dot3v(ax, ay, az, ax, ay, az);
-            const f2v ia = {1.0f / sqrtf(la.x), 1.0f / sqrtf(la.y)};
-            ax *= ia; ay *= ia; az *= ia;
+            const Axis2 n = AXIS_READY ? axis : world_axis2(m0, m1, a0, a1);
             f2v vx = splat(v.cam[0]) - wx, vy = splat(v.cam[1]) - wy, vz = splat(v.cam[2]) - wz;
             const f2v lv = dot3v(vx, vy, vz, vx, vy, vz);
             const f2v iv = {1.0f / sqrtf(lv.x), 1.0f / sqrtf(lv.y)};
             vx *= iv; vy *= iv; vz *= iv;
-            const f2v d = dot3v(ax, ay, az, vx, vy, vz);
+            const f2v d = dot3v(n.x, n.y, n.z, vx, vy, vz);
             if (!k0) k0 = d.x < -a0.w;
             if (!k1) k1 = d.y < -a1.w;
         }
@@ -211,7 +257,14 @@ __device__ __forceinline__ void pair_visible2_impl(const uint32_t TESTS, const V
     if (!CONE_FIRST) cone_test();
     vis0 = !k0;
     vis1 = !k1;
-#undef MCULL_M2
+}
+
+template <bool CONE_FIRST>
+__device__ __forceinline__ void pair_visible2_impl(const uint32_t TESTS, const ViewConst &v, const Xform &m0, const Xform &m1,
+                                                   float scale0, float scale1, float4 a0, float4 a1, float4 c0, float4 c1,
+                                                   bool in0, bool in1, bool &vis0, bool &vis1) {
+    const Centre2 w = world_centre2(m0, m1, scale0, scale1, c0, c1);
+    tests2<CONE_FIRST, false>(TESTS, v, m0, m1, w, Axis2{}, a0, a1, in0, in1, vis0, vis1);
 }
 
 // The tests as a compile-time constant: the single-view kernels are instantiated per combination.
@@ -412,21 +465,44 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         c[k] = load_bounds<NT>(centre_radius + id);
     }
     __syncthreads();
+    // what does not depend on the view is evaluated once per group: the transforms, the world-space
+    // centre and radius, and the unit cone axis (for pairs no view tests with the cone that is wasted
+    // work, amortised over the views)
+    Xform m[NG];
+    float4 wc[NG], wa[NG];  // scalar form
+    Centre2 wc2[NG / 2 + 1];
+    Axis2 wa2[NG / 2 + 1];
+    constexpr bool kPacked = NG % 2 == 0 && NT;
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const uint32_t slot = wave * NG + k;
+        m[k].c0 = s_x[slot][0]; m[k].c1 = s_x[slot][1]; m[k].c2 = s_x[slot][2]; m[k].c3 = s_x[slot][3];
+    }
+    if constexpr (kPacked) {
+#pragma unroll
+        for (int k = 0; k < NG; k += 2) {
+            const uint32_t slot = wave * NG + k;
+            wc2[k / 2] = world_centre2(m[k], m[k + 1], s_scale[slot], s_scale[slot + 1], c[k], c[k + 1]);
+            wa2[k / 2] = world_axis2(m[k], m[k + 1], a[k], a[k + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            wc[k] = world_centre(m[k], s_scale[wave * NG + k], c[k]);
+            wa[k] = world_axis(m[k], a[k]);
+        }
+    }
     for (uint32_t i = 0; i < vs.n; i++) {
         const ViewConst &v = vs.v[i];
         uint64_t *__restrict__ mask = vs.mask[i];
         uint32_t count = 0;
-        if constexpr (NG % 2 == 0 && NT) {
+        if constexpr (kPacked) {
 #pragma unroll
             for (int k = 0; k < NG; k += 2) {
                 const uint32_t slot = wave * NG + k;
-                Xform m0, m1;
-                m0.c0 = s_x[slot][0]; m0.c1 = s_x[slot][1]; m0.c2 = s_x[slot][2]; m0.c3 = s_x[slot][3];
-                m1.c0 = s_x[slot + 1][0]; m1.c1 = s_x[slot + 1][1]; m1.c2 = s_x[slot + 1][2]; m1.c3 = s_x[slot + 1][3];
                 bool vis0, vis1;
                 const uint32_t n0 = s_rec[slot].z, n1 = s_rec[slot + 1].z;
-                pair_visible2_impl<NT>(v.tests, v, m0, m1, s_scale[slot], s_scale[slot + 1], a[k], a[k + 1], c[k], c[k + 1],
-                                       lane < n0, lane < n1, vis0, vis1);
+                tests2<NT, true>(v.tests, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], lane < n0, lane < n1, vis0, vis1);
                 const uint64_t b0 = __ballot(vis0 && lane < n0), b1 = __ballot(vis1 && lane < n1);
                 if (lane == 0 && n0) mask[block_g0 + slot] = b0;
                 if (lane == 0 && n1) mask[block_g0 + slot + 1] = b1;
@@ -436,10 +512,8 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
 #pragma unroll
             for (int k = 0; k < NG; k++) {
                 const uint32_t slot = wave * NG + k;
-                Xform m;
-                m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
                 const uint32_t n_valid = s_rec[slot].z;
-                const bool vis = pair_visible_impl<NT>(v.tests, v, m, s_scale[slot], a[k], c[k]) && (lane < n_valid);
+                const bool vis = pair_visible_prepared<NT>(v.tests, v, m[k], wc[k], wa[k]) && (lane < n_valid);
                 const uint64_t ballot = __ballot(vis);
                 if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
                 count += (uint32_t)__popcll(ballot);
