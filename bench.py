@@ -523,7 +523,7 @@ def run_hiz(env):
 
 def run_bounds(env):
     args, mc, ctx = env.args, env.mc, env.ctx
-    copies = 64
+    copies = args.bounds_copies
     z = np.load(os.path.join(ROOT, "tests", "golden", "kitten_scene.npz"))
     ml, md, vt = z["meshlets"].view(mc.MESHLET), z["meshlet_data"], z["vertices"].view(mc.VERTEX)
     mls = []
@@ -777,6 +777,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="config1: also replay the frame as one captured HIP graph")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bounds-copies", type=int, default=64, help="bounds workload: copies of the kitten fixture")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="control-flow rehearsal only: all ranks share GPU 0, collectives over gloo on host copies")
