@@ -234,7 +234,8 @@ uint64_t mcull_hiz_layout(uint32_t width, uint32_t height, uint32_t *levels,
 
 /* createHiZPyramid + buildHiZPyramid + shaders/shader.comp (Engine.cpp:1658-1685,
  * :1834-1866; shader.comp:12-31): level 0 = copy of depth, level i = 2x2 min of level
- * i-1, all levels in one launch.  `view` selects one of MCULL_MAX_VIEWS pyramid slots. */
+ * i-1; the depth image is read once and every level written once (two launches, where the
+ * reference dispatches once per level).  `view` selects one of MCULL_MAX_VIEWS pyramid slots. */
 int mcull_hiz_build(mcull_ctx *ctx, uint32_t view, const float *depth, uint32_t width,
                     uint32_t height, int mem);
 /* Device pointer of a slot's flat pyramid (layout as mcull_hiz_layout). */

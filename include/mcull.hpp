@@ -152,7 +152,7 @@ public:
     void setInstanceRanges(const std::vector<uint32_t> &offset, const std::vector<uint32_t> &count) {
         MCULL_CHECK(ctx_, mcull_set_instance_ranges(ctx_, offset.data(), count.data(), offset.size()));
     }
-    // binding 5 (shader.task:26): all levels of the pyramid in one launch
+    // binding 5 (shader.task:26): every level of the pyramid from one read of the depth image
     void buildHiZPyramid(const float *depth, uint32_t width, uint32_t height, uint32_t view = 0, bool on_device = false) {
         MCULL_CHECK(ctx_, mcull_hiz_build(ctx_, view, depth, width, height, on_device ? MCULL_MEM_DEVICE : MCULL_MEM_HOST));
     }

@@ -1,7 +1,7 @@
-// Hi-Z min-depth pyramid for gfx950.  Images of at least 32x32 take two launches: a streaming pass
-// over the depth image that produces levels 0-3 from registers (hiz_rows_kernel), then the tiled
-// kernel below applied to level 3, which finishes the pyramid.  Smaller images run the tiled kernel
-// on the depth image itself (levels 0-6) and a one-workgroup launch for the rest.
+// Hi-Z min-depth pyramid for gfx950.  Large images (launch_hiz has the threshold) take two launches:
+// a streaming pass over the depth image that produces levels 0-3 from registers (hiz_rows_kernel),
+// then the tiled kernel below applied to level 3, which finishes the pyramid.  Smaller images run the
+// tiled kernel on the depth image itself (levels 0-6) and a one-workgroup launch for the rest.
 //
 // Reference: shaders/shader.comp:12-31 run once per level with a barrier in between
 // (Engine.cpp:1834-1866): level 0 copies the depth image, level k takes the 2x2 minimum of
@@ -9,11 +9,11 @@
 // every texel of level k depends only on its own aligned 2^k x 2^k block of level 0, so one
 // workgroup can produce levels 0..6 of a 64x64 tile from a single read of the depth image:
 // levels 1-2 in registers (4x4 texels per thread), level 3 from LDS and 4-6 with lane shuffles by
-// the workgroup's first wave.  Each workgroup contributes
-// exactly one level-6 texel; the remaining levels are reduced inside the same launch by the waves
-// that finish last (two tiers of atomic tickets, write-through stores + agent-scope acquire).  min() is written as (y < x ? y : x), GLSL's
-// definition, so the result is bit-identical to the level-by-level evaluation for every input
-// including NaN and signed zero.
+// the workgroup's first wave.  Each workgroup contributes exactly one level-6 texel; the remaining
+// levels are reduced either by a second one-workgroup launch or inside the same launch by the waves
+// that finish last (two tiers of atomic tickets, write-through stores + agent-scope loads).  min() is
+// written as (y < x ? y : x), GLSL's definition, so the result is bit-identical to the
+// level-by-level evaluation for every input including NaN and signed zero.
 #include "mcull_internal.h"
 
 namespace mcull {

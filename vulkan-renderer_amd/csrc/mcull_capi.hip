@@ -230,11 +230,8 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
         return MCULL_E_HIP;
     }
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // Both forms read the depth image once and build levels 0-6 of each 64x64 tile in one workgroup.
-    // Finishing levels >= 7 with a second one-workgroup launch measured faster than or equal to the
-    // in-launch hand-over at every size from 800x600 to 8192^2, so it is the default; the single-launch
-    // form stays selectable for callers that want one dispatch.
-    // evaluation switches for the alternative pyramid schemes (results are identical)
+    // The pyramid scheme is chosen by image size (launch_hiz); these switches force one of the schemes
+    // for evaluation and tests (results are identical)
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
     c->hiz_mode = (single && single[0] == '1') ? 2 : (tiles && tiles[0] == '1') ? 1 : (streamed && streamed[0] == '1') ? 3 : 0;
