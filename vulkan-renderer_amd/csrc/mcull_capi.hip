@@ -54,6 +54,7 @@ struct mcull_ctx {
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
+    bool force_streaming = false;  // MCULL_FORCE_STREAMING=1: the kernels for bounds larger than the caches, whatever the size (tests)
 
     // cull scratch + outputs, one set per view slot: mcull_cull uses slot 0, mcull_cull_views slot i
     // for its i-th view; `cur` is the slot the download / rebase / payload / rasterise calls refer to
@@ -234,6 +235,8 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     // for evaluation and tests (results are identical)
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
+    const char *fs = std::getenv("MCULL_FORCE_STREAMING");
+    c->force_streaming = fs && fs[0] == '1';
     c->hiz_mode = (single && single[0] == '1') ? 2 : (tiles && tiles[0] == '1') ? 1 : (streamed && streamed[0] == '1') ? 3 : 0;
     *out = c;
     return MCULL_OK;
@@ -633,7 +636,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *par
     plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
     plan->two_level = mcull::needs_super_counts(s.n_groups);
     // bounds that cannot stay cache-resident between culls are read with the streaming hint
-    plan->streaming = c->n_meshlets * 32ull > (64ull << 20);
+    plan->streaming = c->force_streaming || c->n_meshlets * 32ull > (64ull << 20);
     if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
