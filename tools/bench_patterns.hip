@@ -75,6 +75,45 @@ __global__ __launch_bounds__(kBlock) void cull_sgpr_xform_kernel(const float4 *_
     }
 }
 
+// Probe for a fused single-pass design: the cull pass that also writes the visible entries, with the
+// list offset of every group given (here precomputed from an earlier run's mask; a real single pass
+// would obtain it by a decoupled look-back over the workgroups).  Measures what fusing could gain.
+template <uint32_t TESTS, int NG>
+__global__ __launch_bounds__(kBlock) void cull_fused_probe(const float4 *__restrict__ cone_axis_w,
+                                                           const float4 *__restrict__ centre_radius,
+                                                           const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
+                                                           const uint4 *__restrict__ group_rec, uint32_t n_groups, ViewConst v,
+                                                           const uint32_t *__restrict__ group_off, mcull_visible *__restrict__ list) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g0 = (blockIdx.x * kWaves + wave) * NG;
+    if (g0 >= n_groups) return;
+    GroupInfo gi[NG];
+    Xform m[NG];
+    float scale[NG];
+    float4 a[NG], c[NG];
+    uint32_t off[NG];
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        gi[k] = group_lookup(min(g0 + k, n_groups - 1u), group_rec, 0u, 0u);
+        if (g0 + k >= n_groups) gi[k].count = 0;
+        m[k] = load_xform(transforms, gi[k].inst);
+        scale[k] = xf_scale[gi[k].inst];
+        off[k] = group_off[min(g0 + k, n_groups - 1u)];
+        const uint32_t last = gi[k].count ? gi[k].count - 1u : 0u;
+        const uint32_t id = gi[k].first_meshlet + (lane < last ? lane : last);
+        a[k] = load_bounds<true>(cone_axis_w + id);
+        c[k] = load_bounds<true>(centre_radius + id);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const bool vis = pair_visible<TESTS, true>(v, m[k], scale[k], a[k], c[k]) && (lane < gi[k].count);
+        const uint64_t ballot = __ballot(vis);
+        if (vis) store_entry<true>(list, (unsigned long long)off[k] + __popcll(ballot & ((1ull << lane) - 1ull)), gi[k].inst,
+                                   gi[k].first_meshlet + lane);
+    }
+}
+
 template <bool STRIDED, int UNROLL, bool NT>
 __global__ __launch_bounds__(kBlock) void read_floor_kernel(const float4 *__restrict__ cone_axis_w,
                                                             const float4 *__restrict__ centre_radius, uint32_t n_groups,
@@ -262,6 +301,17 @@ int main(int argc, char **argv) {
             CK(hipMemsetAsync(total, 0, 8)); CK(hipMemsetAsync(inst_count, 0, (size_t)(n_inst + 1) * 4));
             hipLaunchKernelGGL((cull_atomic_kernel<3, true>), dim3(tiles), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, list, cap, inst_count, total, (uint64_t *)nullptr);
         });
+        // what a fused single pass could reach: per-group list offsets given, entries written by the cull pass itself
+        {
+            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u);
+            std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> ho(n_groups); uint32_t run = 0;
+            for (uint32_t g = 0; g < n_groups; g++) { ho[g] = run; run += (uint32_t)__builtin_popcountll(hm[g]); }
+            uint32_t *goff; CK(hipMalloc(&goff, (size_t)n_groups * 4)); CK(hipMemcpy(goff, ho.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice));
+            timeit("fused probe: cull pass writing the list, offsets given", [&] { hipLaunchKernelGGL((cull_fused_probe<3, 4>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, n_groups, v, goff, list); });
+            CK(hipFree(goff));
+            zero_tc();
+        }
     }
     printf("-- list stores: plain vs non-temporal, effect on the following cull pass\n");
     {
