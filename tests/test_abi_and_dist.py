@@ -1,5 +1,5 @@
 """CPU tests of the boundary (the shared library loads and exports the whole ABI; no compute calls
-without a GPU) and of the multi-rank draw-list gather over gloo with world size 2."""
+without a GPU) and of the multi-rank draw-list gather over gloo with world sizes 2 and 4."""
 import ctypes
 import os
 import re
@@ -159,12 +159,12 @@ def _rank_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten):
-    """world_size 2 over gloo: concatenated lists == the single-rank list, gathered commands ==
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten, world):
+    """world_size 2 and 4 over gloo: concatenated lists == the single-rank list, gathered commands ==
     the single-rank commands (firstTask = exclusive scan in global instance order)."""
     import torch.multiprocessing as mp
 
-    world = 2
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     ml = kitten["meshlets"]
     t = H.update_transforms(64)
