@@ -1,0 +1,42 @@
+// Host-code sanitiser run (not part of the product or of the test suite): the load-time mesh pipeline, the
+// scene cache file (including truncated files) and the per-frame input builders under AddressSanitizer and
+// UndefinedBehaviorSanitizer.  GPU code is not sanitised (and no GPU is needed).  Build + run:
+//   cd vulkan-renderer_amd/csrc && hipcc -O1 -g --offload-arch=gfx950 -ffp-contract=off -std=c++17 \
+//     -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -I../../include ../../tools/asan_host_check.cpp \
+//     *.hip -o /tmp/asan_host_check && ASAN_OPTIONS=detect_leaks=0 /tmp/asan_host_check <file.obj> <scratch dir>
+#include "mcull.h"
+#include <cstdio>
+#include <vector>
+#include <cstring>
+#include <string>
+int main(int argc, char **argv) {
+    if (argc < 3) { printf("usage: %s file.obj scratch_dir\n", argv[0]); return 2; }
+    const std::string out = std::string(argv[2]) + "/out.mcs", cut_path = std::string(argv[2]) + "/cut.mcs";
+    mcull_mesh *m = nullptr;
+    int rc = mcull_mesh_load_obj(argv[1], &m);
+    printf("load %d\n", rc);
+    if (rc) return 1;
+    rc = mcull_mesh_optimize(m); printf("opt %d\n", rc);
+    rc = mcull_mesh_build_meshlets(m); printf("meshlets %d\n", rc);
+    mcull_scene_counts n{}; mcull_mesh_counts(m, &n);
+    printf("v %llu i %llu w %llu m %llu\n", (unsigned long long)n.vertex_count, (unsigned long long)n.index_count, (unsigned long long)n.meshlet_data_words, (unsigned long long)n.meshlet_count);
+    rc = mcull_mesh_save(m, out.c_str()); printf("save %d\n", rc);
+    mcull_scene_counts info{}; rc = mcull_scene_info(out.c_str(), &info); printf("info %d %llu\n", rc, (unsigned long long)info.meshlet_count);
+    std::vector<mcull_vertex> v(info.vertex_count); std::vector<uint32_t> idx(info.index_count), md(info.meshlet_data_words), ro(info.range_count), rcn(info.range_count);
+    std::vector<mcull_meshlet> ml(info.meshlet_count);
+    rc = mcull_scene_load(out.c_str(), v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data()); printf("loadscene %d\n", rc);
+    // truncated / corrupt files
+    FILE *f = fopen(out.c_str(), "rb"); std::vector<char> buf(1 << 20); size_t got = fread(buf.data(), 1, buf.size(), f); fclose(f);
+    for (size_t cut : {size_t(0), size_t(10), size_t(95), size_t(96), size_t(1000), got - 1}) {
+        f = fopen(cut_path.c_str(), "wb"); fwrite(buf.data(), 1, cut, f); fclose(f);
+        rc = mcull_scene_info(cut_path.c_str(), &info);
+        int rc2 = rc ? rc : mcull_scene_load(cut_path.c_str(), v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data());
+        printf("cut %zu -> %d %d\n", cut, rc, rc2);
+    }
+    mcull_mesh_destroy(m);
+    mcull_globals g; mcull_create_globals(nullptr, nullptr, nullptr, 45.f, 0.1f, 800, 600, 1, 326, &g);
+    std::vector<mcull_transform> t(1000); mcull_reference_transforms(1000, 42, t.data());
+    std::vector<mcull_draw_indirect> d(1000); mcull_create_indirect_buffer(1000, 326, 3, d.data());
+    printf("done\n");
+    return 0;
+}
