@@ -25,7 +25,9 @@
 namespace mcull {
 
 constexpr int kRasterBlock = 256;
-constexpr uint32_t kSmallBox = 32;  // pixels a lane rasterises on its own (2 to 32 measured the same on sub-pixel triangles)
+// pixels a lane rasterises on its own: 2 to 128 measure the same on sub-pixel triangles (4096 instances at 4K); with the
+// reference's scene at 800x600 (triangles of tens of pixels) 8 costs 114 us against 77 us for 32, and 128 gains nothing
+constexpr uint32_t kSmallBox = 32;
 
 struct RasterConst {
     float vp[16];  // proj * view, column-major
