@@ -70,3 +70,63 @@ def test_random_scene(mc, O, H, contexts, seed):
         assert np.array_equal(ctx.download_mask(), ref.mask), (seed, tests, compaction)
         check_against_oracle(mc, ctx, ref, n_inst, compaction, stride=stride, offset=offset)
     ctx.set_instance_ranges(None, None)
+
+
+def random_meshlets(mc, rs, n_meshlets, n_vertices, spread):
+    """Meshlets of random triangles over random vertices (not a surface: what matters here is the set of
+    triangle shapes, sizes and depths the rasteriser meets, degenerate ones included)."""
+    verts = np.zeros(n_vertices, dtype=mc.VERTEX)
+    verts["pos"][:, :3] = rs.uniform(-spread, spread, (n_vertices, 3)).astype("<f4")
+    meshlets = np.zeros(n_meshlets, dtype=mc.MESHLET)
+    data = []
+    for m in range(n_meshlets):
+        nv = int(rs.randint(3, 65))
+        nt = int(rs.randint(1, 125))
+        ids = rs.choice(n_vertices, nv, replace=nv > n_vertices).astype("<u4")
+        local = rs.randint(0, nv, (nt, 3)).astype("u1")
+        if nt > 4:
+            local[0] = [0, 0, 1]                      # degenerate: two equal corners
+            local[1] = [2, 2, 2]
+        packed = np.zeros((3 * nt + 3) // 4 * 4, dtype="u1")
+        packed[: 3 * nt] = local.reshape(-1)
+        meshlets[m]["dataOffset"] = sum(len(x) for x in data)
+        meshlets[m]["vertexCount"], meshlets[m]["triangleCount"] = nv, nt
+        data += [ids, packed.view("<u4")]
+    return verts, meshlets, np.concatenate(data).astype("<u4")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_triangles_through_the_rasteriser(mc, O, H, contexts, seed):
+    """Random triangle soups at random scales and cameras - sub-pixel to screen-filling, behind the eye,
+    across the near plane, degenerate - rasterised on the GPU and by the oracle: every pixel bit for bit."""
+    rs = np.random.RandomState(5000 + seed)
+    ctx = contexts[0]
+    n_inst = int(rs.choice([1, 3, 20]))
+    verts, meshlets, data = random_meshlets(mc, rs, int(rs.choice([1, 5, 40])), int(rs.choice([8, 64, 500])),
+                                            float(rs.choice([0.05, 0.5, 3.0])))
+    t = H.synthetic_transforms(n_inst, extent=float(rs.choice([0.5, 4.0])), seed=seed)
+    w, h = int(rs.choice([33, 160, 800])), int(rs.choice([17, 120, 600]))
+    eye = tuple(rs.uniform(-3, 3, 3))  # often inside the soup: triangles cross the near plane and surround the eye
+    g = H.create_globals(eye=eye, centre=tuple(rs.uniform(-1, 1, 3)), fov_deg=float(rs.uniform(30, 110)),
+                         z_near=float(rs.choice([0.01, 0.1])), width=w, height=h, flip_y=bool(rs.rand() < 0.5),
+                         meshlet_count=len(meshlets))
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(meshlets)
+    ctx.upload_geometry(verts, data)
+    ctx.compute_bounds()
+    ctx.upload_transforms(t)
+    ctx.cull(g, tests=0)  # every pair: the rasteriser has to cope with what a cull would have removed
+    lst = ctx.download_list()
+    assert len(lst) == n_inst * len(meshlets)
+    ctx.depth_rasterize(g, w, h)
+    got = ctx.depth_download()
+    with np.errstate(all="ignore"):
+        want = O.rasterize_depth(verts, data, meshlets, t, lst, g, w, h)
+    assert np.array_equal(got.view("<u4"), want.view("<u4")), "seed %d: %d pixels differ" % (seed, (got.view("<u4") != want.view("<u4")).sum())
+    # accumulate a second view into the same image without clearing
+    g2 = H.create_globals(eye=tuple(rs.uniform(-3, 3, 3)), width=w, height=h, meshlet_count=len(meshlets))
+    ctx.cull(g2, tests=0)
+    ctx.depth_rasterize(g2, w, h, clear=False)
+    with np.errstate(all="ignore"):
+        want2 = O.rasterize_depth(verts, data, meshlets, t, lst, g2, w, h, depth=want.copy())
+    assert np.array_equal(ctx.depth_download().view("<u4"), want2.view("<u4"))
