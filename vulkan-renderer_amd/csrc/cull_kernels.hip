@@ -903,9 +903,11 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
                           uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st) {
     const uint32_t tiles = tile_count_for(s.n_groups);
-    // one workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
-    // the tile scan) measured 118 / 152 us against 107 us for the 100 M-pair scene
-    const uint32_t split = 1u;
+    // One workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
+    // the tile scan) measured 118 / 152 us against 107 us for the 100 M-pair scene.  A scene with
+    // fewer tiles than a quarter of the CUs is latency-bound instead, and four workgroups per tile, one
+    // staging round each, halve the pass (the reference's scene, 20 tiles: 5.5 us against 10.4 us).
+    const uint32_t split = tiles <= 64u ? 4u : tiles <= 128u ? 2u : 1u;
     const uint32_t grid = tiles * split;
     if (super_counts) {
         hipLaunchKernelGGL(super_sum_kernel, dim3(super_count_for(s.n_groups)), dim3(kBlock), 0, st, tile_counts, tiles,
