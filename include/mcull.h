@@ -265,6 +265,16 @@ int mcull_cull_views(mcull_ctx *ctx, uint32_t n_views, const mcull_globals *glob
                      mcull_cull_result *results);
 int mcull_select_result(mcull_ctx *ctx, uint32_t view);
 
+/* mcull_cull with the Globals in DEVICE memory: they are read by a kernel when the stream reaches the
+ * call, not by the host when the call is made (the reference pushes its Globals per frame with
+ * vkCmdPushConstants, Engine.cpp:2429-2437, :2535; this is the form of that for a recorded command
+ * stream).  A sequence captured into a HIP graph therefore replays with whatever the buffer holds at
+ * replay time: the camera can move without re-capturing.  The host cannot see globals.meshletCount,
+ * so meshlet_count is passed separately (ignored when instance ranges are set).  Ordered compaction
+ * only.  Results are bit-identical to mcull_cull on the same Globals. */
+int mcull_cull_device_globals(mcull_ctx *ctx, const mcull_globals *device_globals, uint32_t meshlet_count,
+                              const mcull_cull_params *params, mcull_cull_result *result);
+
 /* Multi-GPU: re-emits the indirect commands of the last mcull_cull with
  * firstTask += sum(totals[0..rank)), where `totals` is the device array produced by an
  * all-gather of every rank's *result.total.  No reference counterpart (single GPU). */
@@ -305,6 +315,9 @@ int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
  * (Engine.cpp:2381-2551) without the raster hardware.  Stream-ordered. */
 int mcull_depth_rasterize(mcull_ctx *ctx, const mcull_globals *globals, uint32_t width, uint32_t height, int clear);
 /* Device pointer and size of the image (valid until the next mcull_depth_rasterize with another size). */
+/* The same with the Globals in device memory (see mcull_cull_device_globals). */
+int mcull_depth_rasterize_device_globals(mcull_ctx *ctx, const mcull_globals *device_globals, uint32_t width, uint32_t height,
+                                         int clear);
 int mcull_depth_buffer(mcull_ctx *ctx, const float **device_ptr, uint32_t *width, uint32_t *height);
 /* Host copy, width*height floats. */
 int mcull_depth_download(mcull_ctx *ctx, float *out);

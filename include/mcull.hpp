@@ -209,6 +209,24 @@ public:
         p.tests = MCULL_TEST_ALL;
         return cull(globals, &p);
     }
+    // recordFrame with the Globals in device memory: the whole frame reads them when it executes, so it can be
+    // captured once into a HIP graph (hipStreamBeginCapture on the context's stream) and replayed every frame
+    // after the caller has refreshed the 212 bytes at deviceGlobals - the push constants of a recorded frame.
+    mcull_cull_result recordFrameDeviceGlobals(const Globals *deviceGlobals, uint32_t width, uint32_t height,
+                                               uint32_t prepass_tests = MCULL_TEST_FRUSTUM | MCULL_TEST_CONE, uint32_t view = 0) {
+        mcull_cull_params p{};
+        p.tests = prepass_tests;
+        p.hiz_view = view;
+        mcull_cull_result r{};
+        MCULL_CHECK(ctx_, mcull_cull_device_globals(ctx_, deviceGlobals, static_cast<uint32_t>(meshletCount_), &p, &r));
+        MCULL_CHECK(ctx_, mcull_depth_rasterize_device_globals(ctx_, deviceGlobals, width, height, 1));
+        const float *depth = nullptr;
+        MCULL_CHECK(ctx_, mcull_depth_buffer(ctx_, &depth, nullptr, nullptr));
+        buildHiZPyramid(depth, width, height, view, /*on_device=*/true);
+        p.tests = MCULL_TEST_ALL;
+        MCULL_CHECK(ctx_, mcull_cull_device_globals(ctx_, deviceGlobals, static_cast<uint32_t>(meshletCount_), &p, &r));
+        return r;
+    }
     // scene cache: the arrays of Engine.hpp:215-218 written once, uploaded from the file afterwards
     static void saveScene(const std::string &path, const std::vector<Vertex> &vertices, const std::vector<uint32_t> &indices,
                           const std::vector<uint32_t> &meshletData, const std::vector<Meshlet> &meshlets) {

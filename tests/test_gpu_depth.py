@@ -183,6 +183,72 @@ def test_frame_can_be_captured_as_a_hip_graph(mc, O, kitten, config1):
     c.close()
 
 
+def test_captured_frame_follows_a_moving_camera(mc, O, H, kitten, config1):
+    """Globals in device memory: the frame is captured ONCE and replayed for several cameras, the 212
+    bytes being refreshed between replays; every replay equals the oracle's frame for that camera, and
+    the device-resident form equals the ordinary one bit for bit."""
+    import torch
+
+    t = config1["transforms"][:300]
+    ml = kitten["meshlets"]
+    w, h = 640, 480
+    stream = torch.cuda.Stream()
+    c = mc.Context(0, stream=stream.cuda_stream)
+    c.upload_meshlets(ml)
+    c.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+    c.upload_transforms(t)
+    cameras = [H.create_globals(eye=eye, centre=centre, fov_deg=fov, width=w, height=h, flip_y=flip, meshlet_count=len(ml))
+               for eye, centre, fov, flip in (((2.0, 2.0, 2.0), (0.0, 0.0, 0.0), 45.0, True), ((-6.0, 3.0, 1.0), (1.0, 0.0, 0.5), 60.0, True),
+                                              ((0.5, -9.0, 4.0), (0.0, 0.0, 0.0), 35.0, False), ((0.0, 0.0, 0.0), (3.0, 1.0, 0.0), 90.0, True))]
+    g_dev = torch.zeros(212, dtype=torch.uint8, device="cuda")
+    staged = [torch.from_numpy(np.frombuffer(g.tobytes(), dtype=np.uint8).copy()).cuda() for g in cameras]
+    torch.cuda.synchronize()
+
+    def frame():
+        c.cull_device_globals(g_dev.data_ptr(), len(ml), tests=3)
+        c.depth_rasterize_device_globals(g_dev.data_ptr(), w, h)
+        ptr, _, _ = c.depth_buffer()
+        c.hiz_build(ptr, view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+        c.cull_device_globals(g_dev.data_ptr(), len(ml), tests=7, hiz_view=0, write_mask=True)
+
+    def oracle_frame(g):
+        r1 = O.cull_scene(O.View(g), t, ml, tests=3)
+        img = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, r1.list, g, w, h)
+        return img, O.cull_scene(O.View(g, O.hiz_build(img), w, h), t, ml, tests=7)
+
+    with torch.cuda.stream(stream):
+        g_dev.copy_(staged[0])
+    frame()  # the ordinary run: allocates what the frame needs
+    c.synchronize()
+    img, ref = oracle_frame(cameras[0])
+    assert c.download_count() == ref.total and c.download_list().tobytes() == ref.list.tobytes()
+    assert np.array_equal(c.download_mask(), ref.mask)
+    assert np.array_equal(c.depth_download().view("<u4"), img.view("<u4"))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        frame()
+    totals = []
+    for k in (1, 2, 3, 0, 2):
+        with torch.cuda.stream(stream):
+            g_dev.copy_(staged[k])
+        stream.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        img, ref = oracle_frame(cameras[k])
+        assert c.download_count() == ref.total, k
+        assert c.download_list().tobytes() == ref.list.tobytes(), k
+        assert np.array_equal(c.download_mask(), ref.mask), k
+        assert np.array_equal(c.depth_download().view("<u4"), img.view("<u4")), k
+        cmds = c.download_commands(len(t)).view(mc.CMD).reshape(-1)
+        assert np.array_equal(cmds["taskCount"], ref.commands["taskCount"]) and np.array_equal(cmds["firstTask"], ref.commands["firstTask"])
+        totals.append(ref.total)
+    assert len(set(totals)) >= 3  # the cameras really see different things
+    with pytest.raises(mc.McullError):  # the atomic compaction modes take their constants as kernel arguments only
+        p = mc.CullParams(3, mc.COMPACT_WAVE_ATOMIC, 0, 0, 0, 0, 0, 0, None, 0, None, None)
+        c._chk(mc.lib.mcull_cull_device_globals(c._h, g_dev.data_ptr(), len(ml), p, None))
+    c.close()
+
+
 def test_adversarial_vertices(mc, O, ctx, kitten, H):
     """NaN / infinite / huge vertex positions and singular or NaN transforms: the image still equals
     the oracle's bit for bit (such triangles produce NaN areas or depths and draw nothing, or cover

@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_vertices", "mcull_mesh_indices", "mcull_mesh_meshlet_data", "mcull_mesh_meshlets", "mcull_mesh_upload",
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
+    "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
 ]
 
 
@@ -124,6 +125,8 @@ _sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
 _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
 _sig("mcull_cull_views", _I, [_P, _U32, _P, _P, _P])
 _sig("mcull_select_result", _I, [_P, _U32])
+_sig("mcull_cull_device_globals", _I, [_P, _P, _U32, C.POINTER(CullParams), C.POINTER(CullResult)])
+_sig("mcull_depth_rasterize_device_globals", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
 _sig("mcull_depth_rasterize", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
 _sig("mcull_depth_buffer", _I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
 _sig("mcull_depth_download", _I, [_P, _P])
@@ -388,6 +391,10 @@ class Context:
         g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
         self._chk(lib.mcull_depth_rasterize(self._h, _np_ptr(g), width, height, int(bool(clear))))
 
+    def depth_rasterize_device_globals(self, device_globals_ptr, width, height, clear=True):
+        """depth_rasterize() with the Globals in device memory (see cull_device_globals)."""
+        self._chk(lib.mcull_depth_rasterize_device_globals(self._h, device_globals_ptr, width, height, int(bool(clear))))
+
     def depth_buffer(self):
         """(device pointer, width, height) of the depth image."""
         p, w, h = C.c_void_p(), _U32(), _U32()
@@ -480,6 +487,18 @@ class Context:
                        list_ptr, list_capacity, commands_ptr, total_ptr)
         r = CullResult()
         self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
+        self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
+        return r
+
+    def cull_device_globals(self, device_globals_ptr, meshlet_count, tests=TEST_ALL, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
+                            cmd_stride=0, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
+                            total_ptr=None):
+        """cull() with the 212-byte Globals in device memory, read when the stream reaches the call: a captured
+        HIP graph replays with whatever the buffer then holds.  Ordered compaction only."""
+        p = CullParams(tests, COMPACT_ORDERED, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)), 0,
+                       list_ptr, list_capacity, commands_ptr, total_ptr)
+        r = CullResult()
+        self._chk(lib.mcull_cull_device_globals(self._h, device_globals_ptr, meshlet_count, C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
         return r
 

@@ -339,12 +339,18 @@ __device__ __forceinline__ void store_entry(mcull_visible *__restrict__ list, un
 // Staging the transforms in LDS and fetching them with wave-uniform scalar loads into SGPRs
 // measured the same within run-to-run noise (about 480 us for 100 M pairs); LDS staging keeps the
 // SGPR budget small and replaces 4*NG dependent scalar load chains by one coalesced vector load.
-template <uint32_t TESTS, int NG, bool NT>
+// VP: the view constants are read from device memory (`view_dev`, written by an earlier kernel of the
+// stream) instead of the kernel arguments, and the tests to run come from there too (TESTS is unused):
+// a captured HIP graph can then be replayed with a camera that moves.
+template <uint32_t TESTS, int NG, bool NT, bool VP = false>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
-    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v,
-    uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous) {
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v_arg,
+    uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous,
+    const ViewConst *__restrict__ view_dev) {
+    const ViewConst &v = VP ? *view_dev : v_arg;
+    const uint32_t tests = VP ? v.tests : TESTS;
     constexpr uint32_t kGroups = kWaves * NG;  // groups per workgroup
     __shared__ uint4 s_rec[kGroups];
     __shared__ float4 s_x[kGroups][4];
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
         for (int k = 0; k < NG; k += 2) {  // two groups per step: one pair per vector element
             const uint32_t slot = wave * NG + k;
             bool vis0, vis1;
-            pair_visible2_impl<NT>(TESTS, v, load_xform_lds(slot), load_xform_lds(slot + 1), s_scale[slot], s_scale[slot + 1],
+            pair_visible2_impl<NT>(tests, v, load_xform_lds(slot), load_xform_lds(slot + 1), s_scale[slot], s_scale[slot + 1],
                                    a[k], a[k + 1], c[k], c[k + 1], lane < s_rec[slot].z, lane < s_rec[slot + 1].z, vis0, vis1);
             publish(slot, vis0);
             publish(slot + 1, vis1);
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
 #pragma unroll
         for (int k = 0; k < NG; k++) {
             const uint32_t slot = wave * NG + k;
-            publish(slot, pair_visible<TESTS, NT>(v, load_xform_lds(slot), s_scale[slot], a[k], c[k]));
+            publish(slot, pair_visible_impl<NT>(tests, v, load_xform_lds(slot), s_scale[slot], a[k], c[k]));
         }
     }
     if (lane == 0) s_count[wave] = count;
@@ -852,25 +858,33 @@ bool needs_super_counts(uint64_t n_groups) { return tile_count_for(n_groups) > k
 
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                               hipStream_t st) {
+                               const ViewConst *view_dev, hipStream_t st) {
     const uint32_t per_block = kWaves * NG;
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
+    if (view_dev) {
+        hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
+                           s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
+                           tile_counts, 0u, view_dev);
+        return;
+    }
     MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
                                                      s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
-                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u));
+                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
+                                                     (const ViewConst *)nullptr));
 }
 
+// view_dev != nullptr: the kernels take the view constants (and the tests) from that device record
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                            bool streaming, hipStream_t st) {
+                            bool streaming, hipStream_t st, const ViewConst *view_dev) {
     // groups per wave: more requests in flight per wave for big scenes, enough workgroups to fill
     // 256 CUs for small ones
     if (streaming) {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, st);
-        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, st);
+        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, st);
     } else {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, st);
-        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, st);
-        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, st);
+        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, st);
+        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, st);
     }
     return hipGetLastError();
 }

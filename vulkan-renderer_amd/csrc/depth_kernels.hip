@@ -96,11 +96,14 @@ __device__ __forceinline__ void raster_pixel(const Tri &t, float area, bool tl0,
     atomicMax(dst, bits);
 }
 
+// VP: proj*view is read from a device record written earlier on the stream instead of the kernel
+// arguments (replayable HIP graphs with a moving camera).
+template <bool VP>
 __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     const mcull_visible *__restrict__ list, const unsigned long long *__restrict__ total, uint64_t capacity,
     const mcull_meshlet *__restrict__ meshlets, const uint32_t *__restrict__ meshlet_data,
     const mcull_vertex *__restrict__ vertices, const float *__restrict__ transforms, RasterConst rc,
-    uint32_t *__restrict__ depth_bits) {
+    uint32_t *__restrict__ depth_bits, const ViewConst *__restrict__ view_dev) {
     const uint32_t lane = threadIdx.x & 63u;
     // the wave index is made provably wave-uniform, so that the list entry, the meshlet header and
     // the matrix are fetched with scalar loads into SGPRs
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
         {
             const uint32_t r = lane & 3u, c = (lane >> 2) & 3u;
             const float4 col = *reinterpret_cast<const float4 *>(transforms + (size_t)ent.drawID * 16 + 4 * c);
-            const float a0 = r == 0 ? rc.vp[0] : r == 1 ? rc.vp[1] : r == 2 ? rc.vp[2] : rc.vp[3];
-            const float a1 = r == 0 ? rc.vp[4] : r == 1 ? rc.vp[5] : r == 2 ? rc.vp[6] : rc.vp[7];
-            const float a2 = r == 0 ? rc.vp[8] : r == 1 ? rc.vp[9] : r == 2 ? rc.vp[10] : rc.vp[11];
-            const float a3 = r == 0 ? rc.vp[12] : r == 1 ? rc.vp[13] : r == 2 ? rc.vp[14] : rc.vp[15];
+            const float a0 = VP ? view_dev->vp[r] : r == 0 ? rc.vp[0] : r == 1 ? rc.vp[1] : r == 2 ? rc.vp[2] : rc.vp[3];
+            const float a1 = VP ? view_dev->vp[4 + r] : r == 0 ? rc.vp[4] : r == 1 ? rc.vp[5] : r == 2 ? rc.vp[6] : rc.vp[7];
+            const float a2 = VP ? view_dev->vp[8 + r] : r == 0 ? rc.vp[8] : r == 1 ? rc.vp[9] : r == 2 ? rc.vp[10] : rc.vp[11];
+            const float a3 = VP ? view_dev->vp[12 + r] : r == 0 ? rc.vp[12] : r == 1 ? rc.vp[13] : r == 2 ? rc.vp[14] : rc.vp[15];
             const float el = ((a0 * col.x + a1 * col.y) + a2 * col.z) + a3 * col.w;
 #pragma unroll
             for (int j = 0; j < 16; j++) mvp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(el), j));
@@ -275,9 +278,9 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
                                const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               hipStream_t st) {
+                               hipStream_t st, const ViewConst *view_dev) {
     RasterConst rc;
-    for (int i = 0; i < 16; i++) rc.vp[i] = vp[i];
+    for (int i = 0; i < 16; i++) rc.vp[i] = vp ? vp[i] : 0.0f;
     rc.w = w; rc.h = h;
     rc.wf = (float)w; rc.hf = (float)h;
     rc.small_box = kSmallBox;
@@ -288,13 +291,18 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
         int dev = 0, cus = 256, per_cu = 4;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel, kRasterBlock, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel<false>, kRasterBlock, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         const char *e = std::getenv("MCULL_RASTER_GRID");  // evaluation switch: workgroups in the grid (the image does not depend on it)
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)(cus * per_cu);
     }();
-    hipLaunchKernelGGL(depth_raster_kernel, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
-                       capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth));
+    if (view_dev)
+        hipLaunchKernelGGL(depth_raster_kernel<true>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
+                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth), view_dev);
+    else
+        hipLaunchKernelGGL(depth_raster_kernel<false>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
+                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth),
+                           (const ViewConst *)nullptr);
     return hipGetLastError();
 }
 

@@ -52,6 +52,7 @@ struct mcull_ctx {
     HizSlot hiz[MCULL_MAX_VIEWS];
     DevBuf depth_staging, hiz_counter;
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
+    DevBuf view_dev;  // MCULL_MAX_VIEWS + 1 device-resident ViewConst records (the *_device_globals calls; the last one is the rasteriser's)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
     bool force_streaming = false;  // MCULL_FORCE_STREAMING=1: the kernels for bounds larger than the caches, whatever the size (tests)
@@ -144,22 +145,22 @@ int copy_in(mcull_ctx *c, void *dst, const void *src, size_t bytes, int mem) {
 }
 
 // ---- uniform host math, IEEE binary32, fixed association order, no fused multiply-add ----
-inline float Ec(const float *m, int r, int col) { return m[4 * col + r]; }
+__host__ __device__ inline float Ec(const float *m, int r, int col) { return m[4 * col + r]; }
 
 // proj * view (shader.task:60 evaluates (proj*view)*v): column c of the product is
 // ((P[0]*V[c][0] + P[1]*V[c][1]) + P[2]*V[c][2]) + P[3]*V[c][3]
-void mat4_mul(const float *a, const float *b, float *out) {
+__host__ __device__ inline void mat4_mul(const float *a, const float *b, float *out) {
     float r[16];
     for (int col = 0; col < 4; col++)
         for (int row = 0; row < 4; row++)
             r[4 * col + row] = ((Ec(a, row, 0) * Ec(b, 0, col) + Ec(a, row, 1) * Ec(b, 1, col)) +
                                 Ec(a, row, 2) * Ec(b, 2, col)) + Ec(a, row, 3) * Ec(b, 3, col);
-    std::memcpy(out, r, sizeof r);
+    for (int i = 0; i < 16; i++) out[i] = r[i];
 }
 
 // inverse(view)[3].xyz (shader.task:88-89) by cofactor expansion: inv(r,c) = cof(c,r) * (1/det);
 // 3x3 minors expand along their first row, the determinant along row 0, sums left to right.
-void camera_position(const float *view, float cam[3]) {
+__host__ __device__ inline void camera_position(const float *view, float cam[3]) {
     float cof[4][4];
     for (int i = 0; i < 4; i++) {
         for (int j = 0; j < 4; j++) {
@@ -181,6 +182,21 @@ void camera_position(const float *view, float cam[3]) {
                       Ec(view, 0, 3) * cof[0][3];
     const float inv_det = 1.0f / det;
     for (int r = 0; r < 3; r++) cam[r] = cof[3][r] * inv_det;  // inv(r, 3) = cof(3, r) / det
+}
+
+// The view constants of a cull whose Globals live in device memory: the same uniform expressions as on
+// the host (same functions, same rounding), evaluated by one thread when the stream reaches this point,
+// so that a captured graph picks up whatever Globals the buffer holds at replay time.  `base` carries
+// what the host knows (tests, pyramid, meshlet count).
+__global__ void derive_view_kernel(const mcull_globals *__restrict__ g, mcull::ViewConst base, mcull::ViewConst *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    mcull::ViewConst v = base;
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 4; j++) v.frustum[i][j] = g->frustum[i][j];
+    mat4_mul(g->proj, g->view, v.vp);
+    camera_position(g->view, v.cam);
+    v.proj11 = g->proj[5];
+    *out = v;
 }
 
 uint32_t level_count(uint32_t w, uint32_t h) {
@@ -247,7 +263,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth};
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
         for (DevBuf *b : {&o.mask, &o.tile_counts, &o.super_counts, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
@@ -546,8 +562,10 @@ struct CullPlan {
     uint32_t n_tiles;
 };
 
-int plan_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_ctx::ViewOut &o, CullPlan *plan) {
-    if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
+// g == nullptr: the Globals are in device memory; the view-dependent constants stay zero here (a kernel
+// derives them) and meshlet_count stands in for globals.meshletCount.
+int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, const mcull_cull_params *params, mcull_ctx::ViewOut &o,
+              CullPlan *plan) {
     if (!c->have_bounds) return fail(c, MCULL_E_STATE, "no meshlet bounds uploaded");
     mcull_cull_params &p = plan->p;
     std::memset(&p, 0, sizeof p);
@@ -582,7 +600,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *par
         s.n_groups = c->ranged_groups;
         plan->n_pairs = c->ranged_pairs;
     } else {
-        plan->uniform_count = g->meshletCount;  // shader.task:85
+        plan->uniform_count = g ? g->meshletCount : meshlet_count;  // shader.task:85
         if (plan->uniform_count > c->n_meshlets) return fail(c, MCULL_E_INVALID, "globals.meshletCount exceeds uploaded meshlets");
         s.groups_per_instance = (plan->uniform_count + 63u) / 64u;
         s.n_groups = (uint64_t)s.groups_per_instance * c->n_instances;
@@ -592,10 +610,12 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *par
 
     mcull::ViewConst &v = plan->v;
     v = mcull::ViewConst{};
-    std::memcpy(v.frustum, g->frustum, sizeof v.frustum);
-    mat4_mul(g->proj, g->view, v.vp);
-    camera_position(g->view, v.cam);
-    v.proj11 = g->proj[5];
+    if (g) {
+        std::memcpy(v.frustum, g->frustum, sizeof v.frustum);
+        mat4_mul(g->proj, g->view, v.vp);
+        camera_position(g->view, v.cam);
+        v.proj11 = g->proj[5];
+    }
     v.tests = p.tests;
     v.uniform_count = plan->uniform_count;
     if (p.tests & MCULL_TEST_HIZ) {
@@ -688,13 +708,29 @@ void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *r
 
 }  // namespace
 
-int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
+namespace {
+
+// g_dev != nullptr: the Globals are read on the device when the stream gets there (ordered compaction only)
+int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, uint32_t meshlet_count,
+              const mcull_cull_params *params, mcull_cull_result *result) {
     if (!c) return MCULL_E_INVALID;
+    if (!g && !g_dev) return fail(c, MCULL_E_INVALID, "globals is null");
     HIPCHK(c, hipSetDevice(c->device));
     mcull_ctx::ViewOut &o = c->out[0];
     CullPlan pl;
-    if (int rc = plan_cull(c, g, params, o, &pl)) return rc;
+    if (int rc = plan_cull(c, g, meshlet_count, params, o, &pl)) return rc;
+    const mcull::ViewConst *view_dev = nullptr;
+    if (g_dev) {
+        if (pl.p.compaction != MCULL_COMPACT_ORDERED)
+            return fail(c, MCULL_E_INVALID, "device-resident globals support ordered compaction only");
+        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        view_dev = (const mcull::ViewConst *)c->view_dev.p;
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (view_dev) {
+        hipLaunchKernelGGL(derive_view_kernel, dim3(1), dim3(64), 0, c->stream, g_dev, pl.v, (mcull::ViewConst *)c->view_dev.p);
+        HIPCHK(c, hipGetLastError());
+    }
     if (pl.s.n_groups == 0) {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
         HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
@@ -702,7 +738,7 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
                                               (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
-                                          c->stream));
+                                          c->stream, view_dev));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
@@ -722,6 +758,19 @@ int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *pa
     return MCULL_OK;
 }
 
+}  // namespace
+
+int mcull_cull(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
+    if (c && !g) return fail(c, MCULL_E_INVALID, "globals is null");
+    return cull_impl(c, g, nullptr, 0, params, result);
+}
+
+int mcull_cull_device_globals(mcull_ctx *c, const mcull_globals *device_globals, uint32_t meshlet_count,
+                              const mcull_cull_params *params, mcull_cull_result *result) {
+    if (c && !device_globals) return fail(c, MCULL_E_INVALID, "device_globals is null");
+    return cull_impl(c, nullptr, device_globals, meshlet_count, params, result);
+}
+
 int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, const mcull_cull_params *params,
                      mcull_cull_result *results) {
     if (!c) return MCULL_E_INVALID;
@@ -730,7 +779,7 @@ int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *global
     HIPCHK(c, hipSetDevice(c->device));
     CullPlan pl[MCULL_MAX_VIEWS];
     for (uint32_t i = 0; i < n_views; i++) {
-        if (int rc = plan_cull(c, &globals[i], params ? &params[i] : nullptr, c->out[i], &pl[i])) return rc;
+        if (int rc = plan_cull(c, &globals[i], 0, params ? &params[i] : nullptr, c->out[i], &pl[i])) return rc;
         if (pl[i].p.compaction != MCULL_COMPACT_ORDERED)
             return fail(c, MCULL_E_INVALID, "mcull_cull_views supports ordered compaction only (view %u)", i);
         if (pl[i].uniform_count != pl[0].uniform_count)
@@ -873,10 +922,12 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
 
 // ------------------------------------------------------------------------------------ depth source
 
-int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, uint32_t height, int clear) {
+namespace {
+
+int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, uint32_t width, uint32_t height, int clear) {
     if (!c) return MCULL_E_INVALID;
     mcull_ctx::ViewOut &o = c->out[c->cur];
-    if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
+    if (!g && !g_dev) return fail(c, MCULL_E_INVALID, "globals is null");
     if (width == 0 || height == 0 || width > 16384 || height > 16384) return fail(c, MCULL_E_INVALID, "depth size %ux%u", width, height);
     if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result to rasterise");
     HIPCHK(c, hipSetDevice(c->device));
@@ -891,17 +942,41 @@ int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, 
     c->depth_h = height;
     if (clear || resized) HIPCHK(c, hipMemsetAsync(c->depth.p, 0, bytes, c->stream));  // clear value 0 (Engine.cpp:2404)
     float vp[16];
-    mat4_mul(g->proj, g->view, vp);
+    const mcull::ViewConst *view_dev = nullptr;
+    if (g) {
+        mat4_mul(g->proj, g->view, vp);
+    } else {
+        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        view_dev = (const mcull::ViewConst *)c->view_dev.p + MCULL_MAX_VIEWS;  // the rasteriser's own record
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (view_dev) {
+        hipLaunchKernelGGL(derive_view_kernel, dim3(1), dim3(64), 0, c->stream, g_dev, mcull::ViewConst{},
+                           (mcull::ViewConst *)c->view_dev.p + MCULL_MAX_VIEWS);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, mcull::launch_depth_raster(o.last.list, (const uint64_t *)o.total_ptr, o.last.capacity,
                                          (const mcull_meshlet *)c->aos.p, (const uint32_t *)c->mdata.p,
-                                         (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, vp, width,
-                                         height, (float *)c->depth.p, c->stream));
+                                         (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, g ? vp : nullptr,
+                                         width, height, (float *)c->depth.p, c->stream, view_dev));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;
     }
     return MCULL_OK;
+}
+
+}  // namespace
+
+int mcull_depth_rasterize(mcull_ctx *c, const mcull_globals *g, uint32_t width, uint32_t height, int clear) {
+    if (c && !g) return fail(c, MCULL_E_INVALID, "globals is null");
+    return raster_impl(c, g, nullptr, width, height, clear);
+}
+
+int mcull_depth_rasterize_device_globals(mcull_ctx *c, const mcull_globals *device_globals, uint32_t width, uint32_t height,
+                                         int clear) {
+    if (c && !device_globals) return fail(c, MCULL_E_INVALID, "device_globals is null");
+    return raster_impl(c, nullptr, device_globals, width, height, clear);
 }
 
 int mcull_depth_buffer(mcull_ctx *c, const float **device_ptr, uint32_t *width, uint32_t *height) {

@@ -56,7 +56,7 @@ bool needs_super_counts(uint64_t n_groups);
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st);
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                            bool streaming, hipStream_t st);
+                            bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st);
@@ -87,7 +87,7 @@ hipError_t gpu_build_meshlets(const uint32_t *indices, uint32_t n_tri, std::vect
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
                                const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               hipStream_t st);
+                               hipStream_t st, const ViewConst *view_dev = nullptr);
 
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero)
 constexpr size_t kHizCounterBytes = 2048;
