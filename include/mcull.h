@@ -419,6 +419,47 @@ int mcull_reference_transforms(uint32_t draw_count, uint32_t seed, mcull_transfo
 int mcull_create_indirect_buffer(uint32_t draw_count, uint32_t meshlet_count, uint32_t index_count,
                                  mcull_draw_indirect *out);
 
+/* ------------------------------------------------------------------ several GPUs from one host thread */
+
+/* A group holds one context per shard of a scene (normally one shard per GPU; an ordinal may repeat, which
+ * puts several shards on one GPU), each on a stream of its own, all driven by the calling thread.  The
+ * instances of the scene are split into contiguous ranges, shard r holding the r-th range: upload each
+ * shard's meshlets / transforms / ranges / pyramid through the ordinary calls on mcull_group_ctx(grp, r).
+ * The reference selects a single physical device (Engine.cpp:658-666) and has no counterpart; for one
+ * process per GPU use mcull_rebase_commands with a collective of the caller's instead. */
+#define MCULL_GROUP_MAX_SHARDS 64
+typedef struct mcull_group mcull_group;
+
+typedef struct mcull_group_result {
+    mcull_cull_result local;     /* this shard's own cull: list (drawIDs count from the shard's first instance),
+                                    rank-local commands, count                                              */
+    const void *commands;        /* on this shard's device: the records of ALL instances of the scene in instance
+                                    order; NV records carry firstTask into the concatenation of the shards' lists */
+    const uint32_t *first_task;  /* EXT records only (else NULL): the same offsets, one per instance of the scene */
+    const uint64_t *totals;      /* on this shard's device: n_shards visible counts, then their sum               */
+    uint64_t n_instances;        /* instances of the whole scene                                                   */
+    uint64_t first_instance;     /* global index of this shard's instance 0 (add it to the list's drawIDs)         */
+} mcull_group_result;
+
+int mcull_group_create(const int *device_ordinals, uint32_t n_shards, mcull_group **out);
+int mcull_group_destroy(mcull_group *grp);
+uint32_t mcull_group_size(const mcull_group *grp);
+mcull_ctx *mcull_group_ctx(mcull_group *grp, uint32_t shard);
+const char *mcull_group_last_error(const mcull_group *grp);
+/* mcull_cull on every shard with the same Globals and params (ordered compaction; list / commands / total of
+ * params must be NULL), then one exchange: each shard copies its commands and count straight to every other
+ * device (point to point, one copy per pair), and every device packs what it received into the scene-wide
+ * command buffer with firstTask_i = sum of the visible counts of all instances before i - the buffer one
+ * mcull_cull over the unsharded scene would write.  Asynchronous: results[d] (n_shards entries, may be NULL)
+ * is valid in stream order on shard d's stream and until the next mcull_group_cull. */
+int mcull_group_cull(mcull_group *grp, const mcull_globals *globals, const mcull_cull_params *params,
+                     mcull_group_result *results);
+int mcull_group_synchronize(mcull_group *grp);
+/* Synchronous read-back of one device's copy of the scene-wide result; any pointer may be NULL.
+ * totals receives n_shards + 1 values. */
+int mcull_group_download(mcull_group *grp, uint32_t shard, void *commands, uint64_t command_bytes, uint32_t *first_task,
+                         uint64_t *totals);
+
 #ifdef __cplusplus
 }
 #endif

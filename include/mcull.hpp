@@ -42,6 +42,17 @@
         }                                                                                             \
     } while (0)
 
+#define MCULL_GROUP_CHECK(expr)                                                                       \
+    do {                                                                                              \
+        int mcull_status_ = (expr);                                                                   \
+        if (mcull_status_ != MCULL_OK) {                                                              \
+            std::string mcull_msg_ = std::string("mcull error: ") + mcull_status_string(mcull_status_) + \
+                                     " (" + (grp_ ? mcull_group_last_error(grp_) : "no group") + ")"; \
+            std::cerr << mcull_msg_ << " in " << __FILE__ << " at line " << __LINE__ << std::endl;   \
+            throw std::runtime_error(mcull_msg_);                                                     \
+        }                                                                                             \
+    } while (0)
+
 namespace mcull {
 
 using Vertex = mcull_vertex;
@@ -249,6 +260,75 @@ public:
 private:
     mcull_ctx *ctx_ = nullptr;
     uint64_t meshletCount_ = 0, instances_ = 0;
+};
+
+// One scene over several GPUs from the Engine's single thread (mcull_group_*): the instances are split into
+// contiguous, equally sized ranges, one per device ordinal; every device ends up with the DrawIndirect
+// commands of the whole scene.  The reference draws on one device (Engine.cpp:658-666).
+class MultiGpuCuller {
+public:
+    explicit MultiGpuCuller(const std::vector<int> &deviceOrdinals) {
+        MCULL_GROUP_CHECK(mcull_group_create(deviceOrdinals.data(), (uint32_t)deviceOrdinals.size(), &grp_));
+    }
+    ~MultiGpuCuller() {
+        if (grp_) mcull_group_destroy(grp_);
+    }
+    MultiGpuCuller(const MultiGpuCuller &) = delete;
+    MultiGpuCuller &operator=(const MultiGpuCuller &) = delete;
+
+    uint32_t shardCount() const { return mcull_group_size(grp_); }
+    mcull_ctx *shard(uint32_t r) const { return mcull_group_ctx(grp_, r); }
+    // first instance of shard r when `instances` are split evenly
+    static uint64_t firstInstance(uint64_t instances, uint32_t shards, uint32_t r) { return instances * r / shards; }
+
+    // binding 2 on every device (each shard draws the same meshes)
+    void createMeshletBuffer(const std::vector<Meshlet> &meshlets) {
+        for (uint32_t r = 0; r < shardCount(); r++)
+            MCULL_CHECK(shard(r), mcull_upload_meshlets(shard(r), meshlets.data(), meshlets.size(), MCULL_MEM_HOST));
+    }
+    // the cached scene on every device
+    void loadScene(const std::string &path) {
+        for (uint32_t r = 0; r < shardCount(); r++) MCULL_CHECK(shard(r), mcull_scene_upload(shard(r), path.c_str()));
+    }
+    // binding 4, split: shard r receives transforms [firstInstance(r), firstInstance(r + 1))
+    void updateTransforms(const std::vector<Transform> &transforms) {
+        const uint32_t n = shardCount();
+        for (uint32_t r = 0; r < n; r++) {
+            const uint64_t b = firstInstance(transforms.size(), n, r), e = firstInstance(transforms.size(), n, r + 1);
+            MCULL_CHECK(shard(r), mcull_upload_transforms(shard(r), transforms.data() + b, e - b, MCULL_MEM_HOST));
+        }
+        instances_ = transforms.size();
+    }
+    void buildHiZPyramid(const float *hostDepth, uint32_t width, uint32_t height, uint32_t view = 0) {
+        for (uint32_t r = 0; r < shardCount(); r++)
+            MCULL_CHECK(shard(r), mcull_hiz_build(shard(r), view, hostDepth, width, height, MCULL_MEM_HOST));
+    }
+    // the task-shader work of recordCmdBuffer on every shard + the exchange; results[d] lives on device d
+    std::vector<mcull_group_result> cull(const Globals &g, const mcull_cull_params *params = nullptr) {
+        std::vector<mcull_group_result> res(shardCount());
+        MCULL_GROUP_CHECK(mcull_group_cull(grp_, &g, params, res.data()));
+        stride_ = params && params->cmd_stride ? params->cmd_stride : (params && params->cmd_form == MCULL_CMD_EXT_GROUPS ? 12u : 8u);
+        return res;
+    }
+    // host copy of the scene-wide command records as device `r` holds them
+    std::vector<uint8_t> indirectCommands(uint32_t r) {
+        std::vector<uint8_t> raw(instances_ * stride_);
+        MCULL_GROUP_CHECK(mcull_group_download(grp_, r, raw.data(), raw.size(), nullptr, nullptr));
+        return raw;
+    }
+    // visible counts of the shards, then their sum
+    std::vector<uint64_t> visibleCounts(uint32_t r = 0) {
+        std::vector<uint64_t> totals(shardCount() + 1);
+        MCULL_GROUP_CHECK(mcull_group_download(grp_, r, nullptr, 0, nullptr, totals.data()));
+        return totals;
+    }
+    void waitIdle() { MCULL_GROUP_CHECK(mcull_group_synchronize(grp_)); }
+    mcull_group *handle() const { return grp_; }
+
+private:
+    mcull_group *grp_ = nullptr;
+    uint64_t instances_ = 0;
+    uint32_t stride_ = 8;
 };
 
 }  // namespace mcull

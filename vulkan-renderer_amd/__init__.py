@@ -63,7 +63,10 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
+    "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
+    "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download",
 ]
+GROUP_MAX_SHARDS = 64
 
 
 class CullParams(C.Structure):
@@ -76,6 +79,11 @@ class CullParams(C.Structure):
 class CullResult(C.Structure):
     _fields_ = [("list", C.c_void_p), ("commands", C.c_void_p), ("total", C.c_void_p), ("mask", C.c_void_p),
                 ("n_groups", C.c_uint64), ("n_pairs", C.c_uint64), ("first_task", C.c_void_p)]
+
+
+class GroupResult(C.Structure):
+    _fields_ = [("local", CullResult), ("commands", C.c_void_p), ("first_task", C.c_void_p), ("totals", C.c_void_p),
+                ("n_instances", C.c_uint64), ("first_instance", C.c_uint64)]
 
 
 def _sig(name, restype, argtypes):
@@ -146,6 +154,14 @@ _sig("mcull_create_globals", _I, [_P, _P, _P, C.c_float, C.c_float, _U32, _U32, 
 _sig("mcull_extract_frustum", _I, [_P])
 _sig("mcull_reference_transforms", _I, [_U32, _U32, _P])
 _sig("mcull_create_indirect_buffer", _I, [_U32, _U32, _U32, _P])
+_sig("mcull_group_create", _I, [_P, _U32, C.POINTER(_P)])
+_sig("mcull_group_destroy", _I, [_P])
+_sig("mcull_group_size", _U32, [_P])
+_sig("mcull_group_ctx", _P, [_P, _U32])
+_sig("mcull_group_last_error", C.c_char_p, [_P])
+_sig("mcull_group_cull", _I, [_P, _P, C.POINTER(CullParams), _P])
+_sig("mcull_group_synchronize", _I, [_P])
+_sig("mcull_group_download", _I, [_P, _U32, _P, _U64, _P, _P])
 
 
 class McullError(RuntimeError):
@@ -340,9 +356,19 @@ class Context:
             raise McullError(rc, "mcull_create(device=%d) failed; an MI355X (gfx950) device is required" % device)
         self.device = device
 
+    @classmethod
+    def _borrowed(cls, handle, device):
+        """A Context over a handle somebody else owns (a shard of a Group): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self._h = _P(handle)
+        self._owned = False
+        self.device = device
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            lib.mcull_destroy(self._h)
+            if getattr(self, "_owned", True):
+                lib.mcull_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -572,3 +598,63 @@ class Context:
         ms = C.c_float()
         self._chk(lib.mcull_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class Group:
+    """Several shards of one scene driven by one host thread (mcull_group): shard r holds the r-th contiguous
+    range of the instances; `shards[r]` is its Context for the uploads."""
+
+    def __init__(self, device_ordinals):
+        ords = (C.c_int * len(device_ordinals))(*device_ordinals)
+        self._h = _P()
+        rc = lib.mcull_group_create(C.cast(ords, _P), len(device_ordinals), C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise McullError(rc, "mcull_group_create(%r) failed" % (list(device_ordinals),))
+        self.shards = [Context._borrowed(lib.mcull_group_ctx(self._h, r), d) for r, d in enumerate(device_ordinals)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for s in self.shards:
+                s.close()
+            lib.mcull_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise McullError(rc, lib.mcull_group_last_error(self._h).decode())
+
+    def cull(self, globals_, tests=TEST_ALL, hiz_view=0, cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0,
+             compaction=COMPACT_ORDERED, list_ptr=None):
+        g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
+        p = CullParams(tests, compaction, hiz_view, cmd_form, cmd_stride, cmd_offset, 0, 0, list_ptr, 0, None, None)
+        n = len(self.shards)
+        R = (GroupResult * n)()
+        self._chk(lib.mcull_group_cull(self._h, _np_ptr(g), C.byref(p), C.cast(R, _P)))
+        self._stride = cmd_stride or (12 if cmd_form == CMD_EXT_GROUPS else 8)
+        self._ext = cmd_form == CMD_EXT_GROUPS
+        self._n_instances = int(R[0].n_instances)
+        for s, r in zip(self.shards, R):
+            s._last = (int(r.local.n_groups), int(r.local.n_pairs), cmd_stride)
+        return list(R)
+
+    def synchronize(self):
+        self._chk(lib.mcull_group_synchronize(self._h))
+
+    def download(self, shard):
+        """(commands as raw bytes, first_task or None, totals[n_shards + 1]) as device `shard` holds them."""
+        raw = np.zeros(max(self._n_instances * self._stride, 1), dtype="u1")
+        ft = np.zeros(max(self._n_instances, 1), dtype="<u4") if self._ext else None
+        totals = np.zeros(len(self.shards) + 1, dtype="<u8")
+        self._chk(lib.mcull_group_download(self._h, shard, _np_ptr(raw), self._n_instances * self._stride,
+                                           _np_ptr(ft) if ft is not None else None, _np_ptr(totals)))
+        return raw[: self._n_instances * self._stride], (ft[: self._n_instances] if ft is not None else None), totals

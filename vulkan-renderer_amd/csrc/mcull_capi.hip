@@ -209,6 +209,7 @@ uint32_t level_count(uint32_t w, uint32_t h) {
 
 hipStream_t mcull_ctx_stream(mcull_ctx *ctx) { return ctx->stream; }
 int mcull_ctx_device(mcull_ctx *ctx) { return ctx->device; }
+uint64_t mcull_ctx_instances(mcull_ctx *ctx) { return ctx->n_instances; }
 int mcull_ctx_fail(mcull_ctx *ctx, int code, const char *message) { return fail(ctx, code, "%s", message); }
 
 extern "C" {

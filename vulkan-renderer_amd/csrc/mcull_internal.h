@@ -100,4 +100,5 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
 // Accessors for the sources that work on a context without seeing its definition (mcull_capi.hip).
 hipStream_t mcull_ctx_stream(mcull_ctx *ctx);
 int mcull_ctx_device(mcull_ctx *ctx);
+uint64_t mcull_ctx_instances(mcull_ctx *ctx);
 int mcull_ctx_fail(mcull_ctx *ctx, int code, const char *message);
