@@ -275,6 +275,11 @@ int mcull_select_result(mcull_ctx *ctx, uint32_t view);
 int mcull_cull_device_globals(mcull_ctx *ctx, const mcull_globals *device_globals, uint32_t meshlet_count,
                               const mcull_cull_params *params, mcull_cull_result *result);
 
+/* mcull_cull_views with the n_views Globals in one device array (212-byte records, no padding): the cascade
+ * form of mcull_cull_device_globals, same rules. */
+int mcull_cull_views_device_globals(mcull_ctx *ctx, uint32_t n_views, const mcull_globals *device_globals,
+                                    uint32_t meshlet_count, const mcull_cull_params *params, mcull_cull_result *results);
+
 /* Multi-GPU: re-emits the indirect commands of the last mcull_cull with
  * firstTask += sum(totals[0..rank)), where `totals` is the device array produced by an
  * all-gather of every rank's *result.total.  No reference counterpart (single GPU). */

@@ -90,3 +90,38 @@ def test_views_through_the_streaming_kernels(mc, O, H, sctx, kitten):
     for v in range(6):  # and one view at a time
         sctx.cull(views[v], **params[v])
         compare(mc, sctx, refs[v], n)
+
+
+@pytest.mark.parametrize("streaming", [False, True])
+def test_views_with_globals_in_device_memory(mc, O, H, ctx, sctx, kitten, streaming):
+    """mcull_cull_views_device_globals: the views' Globals sit in one device array and are read when the
+    stream gets to the call; refreshing the array and calling again gives the new cameras' results."""
+    import torch
+
+    c = sctx if streaming else ctx
+    ml = kitten["meshlets"]
+    n, w, h, nv = 120, 640, 360, 5
+    t = H.update_transforms(n)
+    c.set_instance_ranges(None, None)
+    c.upload_meshlets(ml)
+    c.upload_transforms(t)
+    params, pyrs = [], []
+    for v in range(nv):
+        depth = H.synthetic_depth(w, h, n_discs=20, seed=80 + v)
+        c.hiz_build(depth, view=v)
+        pyrs.append(O.hiz_build(depth))
+        params.append(dict(tests=[7, 3, 5, 6, 1][v], hiz_view=v, write_mask=True))
+    g_dev = torch.zeros(nv * mc.GLOBALS.itemsize, dtype=torch.uint8, device="cuda:0")
+    for frame in range(2):
+        views = []
+        for v in range(nv):
+            ang = 2 * np.pi * v / nv + 0.4 * frame
+            views.append(H.create_globals(eye=(9 * np.cos(ang), 9 * np.sin(ang), 3.0 + v), fov_deg=40.0 + 5 * v, width=w,
+                                          height=h, flip_y=bool(v & 1), meshlet_count=len(ml)))
+        packed = np.concatenate([np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1) for g in views])
+        g_dev.copy_(torch.from_numpy(packed.view("u1").reshape(-1).copy()))
+        torch.cuda.synchronize()
+        c.cull_views(nv, params, device_globals_ptr=g_dev.data_ptr(), meshlet_count=len(ml))
+        for v in range(nv):
+            c.select_result(v)
+            compare(mc, c, O.cull_scene(O.View(views[v], pyrs[v], w, h), t, ml, tests=params[v]["tests"]), n)

@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
+    "mcull_cull_views_device_globals",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download",
 ]
@@ -132,6 +133,7 @@ _sig("mcull_scene_info", _I, [C.c_char_p, C.POINTER(SceneInfo)])
 _sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
 _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
 _sig("mcull_cull_views", _I, [_P, _U32, _P, _P, _P])
+_sig("mcull_cull_views_device_globals", _I, [_P, _U32, _P, _U32, _P, _P])
 _sig("mcull_select_result", _I, [_P, _U32])
 _sig("mcull_cull_device_globals", _I, [_P, _P, _U32, C.POINTER(CullParams), C.POINTER(CullResult)])
 _sig("mcull_depth_rasterize_device_globals", _I, [_P, _P, C.c_uint32, C.c_uint32, _I])
@@ -528,13 +530,16 @@ class Context:
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
         return r
 
-    def cull_views(self, globals_list, params_list=None):
+    def cull_views(self, globals_list, params_list=None, device_globals_ptr=None, meshlet_count=0):
         """One pass for several views.  params_list: dicts with the keyword arguments of cull()
-        (tests, hiz_view, cmd_*, write_mask, list_ptr, list_capacity, commands_ptr, total_ptr)."""
-        n = len(globals_list)
-        g = np.zeros(n, dtype=GLOBALS)
-        for i, x in enumerate(globals_list):
-            g[i] = np.ascontiguousarray(x, dtype=GLOBALS).reshape(1)[0]
+        (tests, hiz_view, cmd_*, write_mask, list_ptr, list_capacity, commands_ptr, total_ptr).
+        With device_globals_ptr, globals_list is just the number of views (or a list of that length) and the
+        Globals are read from that device array of 212-byte records when the stream reaches the call."""
+        n = globals_list if isinstance(globals_list, int) else len(globals_list)
+        if device_globals_ptr is None:
+            g = np.zeros(n, dtype=GLOBALS)
+            for i, x in enumerate(globals_list):
+                g[i] = np.ascontiguousarray(x, dtype=GLOBALS).reshape(1)[0]
         P = (CullParams * n)()
         for i in range(n):
             d = dict(tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0,
@@ -544,7 +549,10 @@ class Context:
             P[i] = CullParams(d["tests"], d["compaction"], d["hiz_view"], d["cmd_form"], d["cmd_stride"], d["cmd_offset"],
                               int(bool(d["write_mask"])), 0, d["list_ptr"], d["list_capacity"], d["commands_ptr"], d["total_ptr"])
         R = (CullResult * n)()
-        self._chk(lib.mcull_cull_views(self._h, n, _np_ptr(g), C.cast(P, _P), C.cast(R, _P)))
+        if device_globals_ptr is None:
+            self._chk(lib.mcull_cull_views(self._h, n, _np_ptr(g), C.cast(P, _P), C.cast(R, _P)))
+        else:
+            self._chk(lib.mcull_cull_views_device_globals(self._h, n, device_globals_ptr, meshlet_count, C.cast(P, _P), C.cast(R, _P)))
         self._views = [(int(r.n_groups), int(r.n_pairs)) for r in R]
         self._last = (self._views[0][0], self._views[0][1], 0)
         return list(R)

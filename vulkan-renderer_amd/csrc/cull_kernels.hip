@@ -436,11 +436,14 @@ struct ViewSet {
     uint32_t n;
 };
 
-template <int NG, bool NT>
+// VP: view i's constants are read from view_dev[i] (device memory, written by an earlier kernel of the stream)
+// instead of the argument segment; masks, counters and the uniform meshlet count still come from `vs`.
+template <int NG, bool NT, bool VP = false>
 __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
-    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewSet vs) {
+    const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewSet vs,
+    const ViewConst *__restrict__ view_dev) {
     constexpr uint32_t kGroups = kWaves * NG;
     __shared__ uint4 s_rec[kGroups];
     __shared__ float4 s_x[kGroups][4];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         }
     }
     for (uint32_t i = 0; i < vs.n; i++) {
-        const ViewConst &v = vs.v[i];
+        const ViewConst &v = VP ? view_dev[i] : vs.v[i];
         uint64_t *__restrict__ mask = vs.mask[i];
         uint32_t count = 0;
         if constexpr (kPacked) {
@@ -890,7 +893,7 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
 }
 
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
-                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st) {
+                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev) {
     ViewSet vs;
     std::memset(&vs, 0, sizeof vs);
     vs.n = n_views;
@@ -903,12 +906,17 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
     // the single-view kernel hides with four groups in flight
     const uint32_t per_block = kWaves * 2;
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
-    if (streaming)
-        hipLaunchKernelGGL((cull_mask_views_kernel<2, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
-                           s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs);
-    else
-        hipLaunchKernelGGL((cull_mask_views_kernel<2, false>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
-                           s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs);
+#define MCULL_LAUNCH_VIEWS(NT_, VP_)                                                                                   \
+    hipLaunchKernelGGL((cull_mask_views_kernel<2, NT_, VP_>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, \
+                       s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs, view_dev)
+    if (view_dev) {
+        if (streaming) MCULL_LAUNCH_VIEWS(true, true);
+        else MCULL_LAUNCH_VIEWS(false, true);
+    } else {
+        if (streaming) MCULL_LAUNCH_VIEWS(true, false);
+        else MCULL_LAUNCH_VIEWS(false, false);
+    }
+#undef MCULL_LAUNCH_VIEWS
     return hipGetLastError();
 }
 

@@ -772,21 +772,37 @@ int mcull_cull_device_globals(mcull_ctx *c, const mcull_globals *device_globals,
     return cull_impl(c, nullptr, device_globals, meshlet_count, params, result);
 }
 
-int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, const mcull_cull_params *params,
-                     mcull_cull_result *results) {
+namespace {
+
+// globals_dev != nullptr: n_views Globals in device memory, read when the stream gets there
+int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, const mcull_globals *globals_dev,
+               uint32_t meshlet_count, const mcull_cull_params *params, mcull_cull_result *results) {
     if (!c) return MCULL_E_INVALID;
     if (n_views == 0 || n_views > MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "n_views must be 1..%d", MCULL_MAX_VIEWS);
-    if (!globals) return fail(c, MCULL_E_INVALID, "globals is null");
+    if (!globals && !globals_dev) return fail(c, MCULL_E_INVALID, "globals is null");
     HIPCHK(c, hipSetDevice(c->device));
     CullPlan pl[MCULL_MAX_VIEWS];
     for (uint32_t i = 0; i < n_views; i++) {
-        if (int rc = plan_cull(c, &globals[i], 0, params ? &params[i] : nullptr, c->out[i], &pl[i])) return rc;
+        if (int rc = plan_cull(c, globals ? &globals[i] : nullptr, meshlet_count, params ? &params[i] : nullptr, c->out[i], &pl[i]))
+            return rc;
         if (pl[i].p.compaction != MCULL_COMPACT_ORDERED)
             return fail(c, MCULL_E_INVALID, "mcull_cull_views supports ordered compaction only (view %u)", i);
         if (pl[i].uniform_count != pl[0].uniform_count)
             return fail(c, MCULL_E_INVALID, "view %u: globals.meshletCount differs from view 0", i);
     }
+    const mcull::ViewConst *view_dev = nullptr;
+    if (globals_dev) {
+        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        view_dev = (const mcull::ViewConst *)c->view_dev.p;
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (view_dev) {
+        for (uint32_t i = 0; i < n_views; i++) {
+            hipLaunchKernelGGL(derive_view_kernel, dim3(1), dim3(64), 0, c->stream, globals_dev + i, pl[i].v,
+                               (mcull::ViewConst *)c->view_dev.p + i);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
     if (pl[0].s.n_groups == 0) {
         for (uint32_t i = 0; i < n_views; i++) {
             mcull_ctx::ViewOut &o = c->out[i];
@@ -806,7 +822,7 @@ int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *global
             masks[i] = (uint64_t *)c->out[i].mask.p;
             counts[i] = (uint32_t *)c->out[i].tile_counts.p;
         }
-        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream));
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev));
         for (uint32_t i = 0; i < n_views; i++)
             if (int rc = launch_ordered_tail(c, c->out[i], pl[i])) return rc;
     }
@@ -817,6 +833,20 @@ int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *global
     for (uint32_t i = 0; i < n_views; i++) finish_cull(c->out[i], pl[i], results ? &results[i] : nullptr);
     c->cur = 0;
     return MCULL_OK;
+}
+
+}  // namespace
+
+int mcull_cull_views(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, const mcull_cull_params *params,
+                     mcull_cull_result *results) {
+    if (c && !globals) return fail(c, MCULL_E_INVALID, "globals is null");
+    return views_impl(c, n_views, globals, nullptr, 0, params, results);
+}
+
+int mcull_cull_views_device_globals(mcull_ctx *c, uint32_t n_views, const mcull_globals *device_globals, uint32_t meshlet_count,
+                                    const mcull_cull_params *params, mcull_cull_result *results) {
+    if (c && !device_globals) return fail(c, MCULL_E_INVALID, "device_globals is null");
+    return views_impl(c, n_views, nullptr, device_globals, meshlet_count, params, results);
 }
 
 int mcull_select_result(mcull_ctx *c, uint32_t view) {

@@ -54,7 +54,8 @@ uint32_t super_count_for(uint64_t n_groups);
 bool needs_super_counts(uint64_t n_groups);
 // One pass over the scene for n_views views (ordered path only): views[i] -> masks[i], tile_counts[i].
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
-                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st);
+                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st,
+                                  const ViewConst *view_dev = nullptr);
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
