@@ -2,6 +2,8 @@
 overlapping meshlet ranges, cameras, projection flips, pyramid sizes (odd ones included), test
 combinations, compaction modes, command layouts, and both kernel families (cache-resident and
 streamed bounds).  Everything is compared bit for bit; the atomic compaction modes after sorting."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,11 +11,12 @@ from test_gpu_parity import check_against_oracle
 
 pytestmark = pytest.mark.gpu
 
+# a longer soak than the default run: MCULL_FUZZ_SCALE=20 runs 20 times as many seeds
+_SCALE = int(os.environ.get("MCULL_FUZZ_SCALE", "1"))
+
 
 @pytest.fixture(scope="module")
 def contexts(mc):
-    import os
-
     plain = mc.Context(0)
     os.environ["MCULL_FORCE_STREAMING"] = "1"
     try:
@@ -25,7 +28,7 @@ def contexts(mc):
     streamed.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_random_scene(mc, O, H, contexts, seed):
     rs = np.random.RandomState(1000 + seed)
     ctx = contexts[seed & 1]
@@ -95,7 +98,7 @@ def random_meshlets(mc, rs, n_meshlets, n_vertices, spread):
     return verts, meshlets, np.concatenate(data).astype("<u4")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SCALE))
 def test_random_triangles_through_the_rasteriser(mc, O, H, contexts, seed):
     """Random triangle soups at random scales and cameras - sub-pixel to screen-filling, behind the eye,
     across the near plane, degenerate - rasterised on the GPU and by the oracle: every pixel bit for bit."""
@@ -130,3 +133,20 @@ def test_random_triangles_through_the_rasteriser(mc, O, H, contexts, seed):
     with np.errstate(all="ignore"):
         want2 = O.rasterize_depth(verts, data, meshlets, t, lst, g2, w, h, depth=want.copy())
     assert np.array_equal(ctx.depth_download().view("<u4"), want2.view("<u4"))
+
+
+def test_mask_of_a_scene_without_groups(mc, O, H, contexts):
+    """Found by the long soak (seed 39): every instance owns zero meshlets, a mask is asked for - it has zero words."""
+    ctx = contexts[0]
+    cone, sphere = H.synthetic_bounds(64, seed=1)
+    t = H.synthetic_transforms(2, extent=3.0, seed=2)
+    ctx.upload_bounds_soa(cone, sphere)
+    ctx.upload_transforms(t)
+    ctx.set_instance_ranges(np.array([3, 9], dtype="<u4"), np.zeros(2, dtype="<u4"))
+    g = H.create_globals(meshlet_count=64)
+    for compaction in (0, 1, 2):
+        r = ctx.cull(g, tests=3, compaction=compaction, write_mask=True)
+        assert r.n_groups == 0 and not r.mask
+        assert len(ctx.download_mask()) == 0 and ctx.download_count() == 0 and len(ctx.download_list()) == 0
+        assert not ctx.download_commands(2).any()
+    ctx.set_instance_ranges(None, None)

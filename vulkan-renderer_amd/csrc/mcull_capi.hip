@@ -693,13 +693,13 @@ void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *r
     o.last.list = pl.list;
     o.last.capacity = pl.capacity;
     o.last.commands = pl.commands;
-    o.last.have_mask = pl.want_mask && pl.s.n_groups > 0;
+    o.last.have_mask = pl.want_mask;  // a scene without any group has a mask of zero words
     o.last.n_pairs = pl.n_pairs;
     if (result) {
         result->list = pl.list;
         result->commands = pl.commands;
         result->total = (const uint64_t *)pl.total;
-        result->mask = o.last.have_mask ? (const uint64_t *)o.mask.p : nullptr;
+        result->mask = (o.last.have_mask && pl.s.n_groups > 0) ? (const uint64_t *)o.mask.p : nullptr;
         result->n_groups = pl.s.n_groups;
         result->n_pairs = pl.n_pairs;
         result->first_task =
