@@ -150,3 +150,39 @@ def test_mask_of_a_scene_without_groups(mc, O, H, contexts):
         assert len(ctx.download_mask()) == 0 and ctx.download_count() == 0 and len(ctx.download_list()) == 0
         assert not ctx.download_commands(2).any()
     ctx.set_instance_ranges(None, None)
+
+
+@pytest.fixture(scope="module")
+def hiz_contexts(mc):
+    out = [mc.Context(0)]
+    for switch in ("MCULL_HIZ_TILES", "MCULL_HIZ_SINGLE_LAUNCH", "MCULL_HIZ_STREAM"):
+        os.environ[switch] = "1"
+        try:
+            out.append(mc.Context(0))
+        finally:
+            del os.environ[switch]
+    yield out
+    for c in out:
+        c.close()
+
+
+@pytest.mark.parametrize("seed", range(6 * _SCALE))
+def test_random_pyramids(mc, O, hiz_contexts, seed):
+    """Random image sizes (tiny, odd, one-texel-wide, wider than a tile row) with special values, through the
+    size-chosen scheme and each forced one, two builds into the same slot: every level bit for bit."""
+    rs = np.random.RandomState(9000 + seed)
+    w = int(rs.choice([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 511, 777, 1024, 1500, 2049]))
+    h = int(rs.choice([1, 2, 4, 7, 31, 32, 33, 64, 65, 127, 128, 129, 300, 513, 1000]))
+    slot = int(rs.randint(0, mc.MAX_VIEWS))
+    for build in range(2):
+        depth = rs.uniform(0, 1, (h, w)).astype("<f4")
+        k = min(h * w, 12)
+        depth.flat[rs.choice(h * w, k, replace=False)] = rs.choice(
+            np.array([np.nan, -0.0, 0.0, np.inf, -np.inf, 1e-40, -1e-40, 1.0, 0.5, 2.0, -1.0, 3e38], dtype="<f4"), k)
+        ref = O.hiz_levels(O.hiz_build(depth), w, h)
+        for c in hiz_contexts:
+            c.hiz_build(depth, view=slot)
+            got = c.hiz_download(view=slot)
+            assert len(got) == len(ref)
+            for lvl, (a, b) in enumerate(zip(got, ref)):
+                assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "seed %d %dx%d level %d" % (seed, w, h, lvl)

@@ -1,9 +1,12 @@
 """GPU half of the mesh pipeline: mcull_mesh_upload completes the product-built meshlets with the
 bounds kernel; the result equals the oracle's CPU pipeline bit for bit and culls identically."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_SCALE = int(os.environ.get("MCULL_FUZZ_SCALE", "1"))  # a longer soak than the default run
 
 
 def test_mesh_upload_completes_bounds_and_culls(mc, O, H, ctx):
@@ -31,6 +34,8 @@ def test_mesh_upload_completes_bounds_and_culls(mc, O, H, ctx):
 
 def _soup(seed, n_pos=300, n_tri=1500):
     rs = np.random.RandomState(seed)
+    if seed >= 4:  # the soak's extra seeds also vary the sizes
+        n_pos, n_tri = int(rs.choice([40, 300, 2000])), int(rs.choice([25, 700, 1500, 6000]))
     pos = rs.randint(-4, 5, (n_pos, 3)).astype("<f4") * 0.25
     pos[pos == 0] *= rs.choice([1.0, -1.0], size=(pos == 0).sum())
     if seed % 2:
@@ -48,7 +53,7 @@ def _soup(seed, n_pos=300, n_tri=1500):
     return pos, cor, nrm, uv
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
 def test_gpu_dedup_and_meshlets_equal_the_host_pipeline_on_soups(mc, ctx, seed):
     """Seams, -0/+0, NaN positions, degenerate triangles, half overflow: the GPU dedup pass numbers
     vertices exactly like the sequential loop, and the GPU meshlet builder cuts the same meshlets."""
@@ -65,7 +70,7 @@ def test_gpu_dedup_and_meshlets_equal_the_host_pipeline_on_soups(mc, ctx, seed):
         assert np.array_equal(gpu.meshlet_data, host.meshlet_data)
         ctx.upload_mesh(host)                      # completes the host mesh's bounds on the GPU
         assert gpu.meshlets.tobytes() == host.meshlets.tobytes()
-        assert len(gpu.meshlets) > 10 and gpu.meshlets["radius"].any()
+        assert seed >= 4 or (len(gpu.meshlets) > 10 and gpu.meshlets["radius"].any())
 
 
 def test_gpu_mesh_front_half_large(mc, O, H, ctx):
