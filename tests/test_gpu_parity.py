@@ -461,3 +461,59 @@ def test_adversarial_bounds_and_transforms(mc, O, ctx, H):
                     assert np.array_equal(ctx.download_mask(), ref.mask), (flip, tests, compaction)
                     check_against_oracle(mc, ctx, ref, n_inst, compaction)
     ctx.set_instance_ranges(None, None)
+
+
+def test_hostile_arguments_on_a_live_context(mc, kitten, config1):
+    """Bad sizes, flags, indices and orders of calls on a working context: an error code and a message each
+    time, and the context keeps working afterwards."""
+    import ctypes as C
+
+    g, t = config1["globals"], config1["transforms"]
+    ml = np.ascontiguousarray(kitten["meshlets"])
+    ctx = mc.Context(0)
+    h = ctx._h
+    L = mc.lib
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    gg = np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1)
+    depth = np.zeros((4, 4), "<f4")
+    res = mc.CullResult()
+    # before anything is uploaded
+    assert L.mcull_cull(h, ptr(gg), None, C.byref(res)) == mc.E_STATE
+    assert L.mcull_download_count(h, C.byref(C.c_uint64())) == mc.E_STATE
+    assert L.mcull_compute_bounds(h) == mc.E_STATE
+    assert L.mcull_depth_rasterize(h, ptr(gg), 64, 64, 1) == mc.E_STATE
+    assert L.mcull_select_result(h, 3) == mc.E_STATE and L.mcull_select_result(h, 99) == mc.E_INVALID
+    assert L.mcull_rebase_commands(h, None, 0) == mc.E_STATE
+    # sizes and flags
+    assert L.mcull_upload_meshlets(h, ptr(ml), len(ml), 7) == mc.E_INVALID            # unknown memory kind
+    assert L.mcull_upload_meshlets(h, ptr(ml), 1 << 44, mc.MEM_HOST) in (mc.E_NOMEM, mc.E_INVALID, mc.E_HIP)
+    assert b"" != L.mcull_last_error(h)
+    assert L.mcull_hiz_build(h, 0, ptr(depth), 0, 4, mc.MEM_HOST) == mc.E_INVALID     # empty image
+    assert L.mcull_hiz_build(h, mc.MAX_VIEWS, ptr(depth), 4, 4, mc.MEM_HOST) == mc.E_INVALID
+    assert L.mcull_hiz_build(h, 0, ptr(depth), 1 << 20, 1 << 20, mc.MEM_HOST) == mc.E_INVALID
+    assert L.mcull_hiz_download_level(h, 0, 0, ptr(depth)) == mc.E_STATE              # nothing built in that slot
+    # the context still works
+    ctx.upload_meshlets(ml)
+    ctx.upload_transforms(t)
+    p = mc.CullParams()
+    p.tests = 8                                                                       # unknown test bit
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.E_INVALID
+    p.tests, p.compaction = 3, 9
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.E_INVALID
+    p.compaction, p.cmd_form = 0, 5
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.E_INVALID
+    p.cmd_form, p.cmd_stride, p.cmd_offset = 0, 8, 4                                   # the record does not fit its stride
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.E_INVALID
+    p.cmd_stride, p.cmd_offset = 0, 0
+    assert L.mcull_cull_views(h, 0, ptr(gg), None, None) == mc.E_INVALID
+    assert L.mcull_cull_views(h, mc.MAX_VIEWS + 1, ptr(gg), None, None) == mc.E_INVALID
+    assert L.mcull_depth_rasterize(h, ptr(gg), 0, 64, 1) == mc.E_INVALID
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.OK
+    assert L.mcull_depth_rasterize(h, ptr(gg), 64, 64, 1) == mc.E_STATE                # no geometry uploaded
+    assert L.mcull_download_commands(h, ptr(depth), 1 << 40) == mc.E_INVALID          # more than the buffer holds
+    p.compaction = mc.COMPACT_WAVE_ATOMIC                                              # a cull that keeps no mask
+    assert L.mcull_cull(h, ptr(gg), C.byref(p), C.byref(res)) == mc.OK and not res.mask
+    assert L.mcull_download_mask(h, ptr(depth), 1) == mc.E_STATE
+    assert L.mcull_emit_task_payloads(h, ptr(depth)) == mc.E_STATE
+    assert ctx.download_count() > 0
+    ctx.close()

@@ -132,7 +132,10 @@ void invalidate_results(mcull_ctx *c) {
     c->cur = 0;
 }
 
+inline bool mem_kind_ok(int mem) { return mem == MCULL_MEM_HOST || mem == MCULL_MEM_DEVICE; }
+
 int copy_in(mcull_ctx *c, void *dst, const void *src, size_t bytes, int mem) {
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
     if (bytes == 0) return MCULL_OK;
     if (mem == MCULL_MEM_HOST) {
         // the caller may free / reuse a host pointer as soon as the call returns
@@ -288,6 +291,8 @@ int mcull_synchronize(mcull_ctx *c) {
 int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t count, int mem) {
     if (!c) return MCULL_E_INVALID;
     if (!meshlets && count) return fail(c, MCULL_E_INVALID, "meshlets is null");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
+    if (count > 0xffffffffull) return fail(c, MCULL_E_INVALID, "meshlet ids are 32-bit: at most 2^32 meshlets");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->aos, count * sizeof(mcull_meshlet)))) return rc;
@@ -310,6 +315,8 @@ int mcull_upload_bounds_soa(mcull_ctx *c, const float *cone_axis_w, const float 
                             int mem, int adopt) {
     if (!c) return MCULL_E_INVALID;
     if ((!cone_axis_w || !centre_radius) && count) return fail(c, MCULL_E_INVALID, "null bounds stream");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
+    if (count > 0xffffffffull) return fail(c, MCULL_E_INVALID, "meshlet ids are 32-bit: at most 2^32 meshlets");
     HIPCHK(c, hipSetDevice(c->device));
     if (adopt && mem == MCULL_MEM_DEVICE) {
         if ((reinterpret_cast<uintptr_t>(cone_axis_w) | reinterpret_cast<uintptr_t>(centre_radius)) & 15u)
@@ -337,6 +344,9 @@ int mcull_upload_geometry(mcull_ctx *c, const mcull_vertex *vertices, uint64_t v
                           const uint32_t *meshlet_data, uint64_t word_count, int mem) {
     if (!c) return MCULL_E_INVALID;
     if ((!vertices && vertex_count) || (!meshlet_data && word_count)) return fail(c, MCULL_E_INVALID, "null geometry");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
+    if (vertex_count > 0xffffffffull || word_count > 0xffffffffull)
+        return fail(c, MCULL_E_INVALID, "vertex ids and data offsets are 32-bit: at most 2^32 vertices / words");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->vertices, vertex_count * sizeof(mcull_vertex)))) return rc;
@@ -410,6 +420,7 @@ int mcull_upload_transforms(mcull_ctx *c, const mcull_transform *transforms, uin
     if (!c) return MCULL_E_INVALID;
     if (!transforms && count) return fail(c, MCULL_E_INVALID, "transforms is null");
     if (count >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "too many instances");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->transforms, count * sizeof(mcull_transform)))) return rc;
@@ -485,6 +496,7 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
     if (!c) return MCULL_E_INVALID;
     if (view >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view slot %u out of range", view);
     if (!depth || width == 0 || height == 0) return fail(c, MCULL_E_INVALID, "empty depth image");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
     if (level_count(width, height) > MCULL_MAX_HIZ_LEVELS) return fail(c, MCULL_E_INVALID, "depth image too large");
     HIPCHK(c, hipSetDevice(c->device));
     HizSlot &s = c->hiz[view];
