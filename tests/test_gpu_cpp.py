@@ -1,6 +1,7 @@
-"""The C++ host mirror (include/mcull.hpp) end to end on the GPU: a small program built with g++
+"""The C++ host mirror (include/mcull.hpp) end to end on the GPU: examples/engine_frame.cpp, built with g++,
 loads a scene cache file, records one frame with the reference-named methods and prints the visible
-count and FNV-1a hashes of the draw list and commands, which must equal the oracle's frame."""
+count and FNV-1a hashes of the draw list and commands, which must equal the oracle's frame; it also replays
+the frame as a HIP graph under a moving camera and splits the scene over three shards."""
 import os
 import subprocess
 
@@ -10,84 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SRC = r"""
-#include "mcull.hpp"
-#include <hip/hip_runtime_api.h>
-#include <cstdio>
-#include <cstring>
-#include <fstream>
-static uint64_t fnv(const void *p, size_t n) {
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; i++) { h ^= static_cast<const unsigned char *>(p)[i]; h *= 1099511628211ull; }
-    return h;
-}
-static bool operator!=(const std::vector<mcull::Transform> &a, const std::vector<mcull::Transform> &b) {
-    return a.size() != b.size() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) != 0;
-}
-template <typename T> static std::vector<T> slurp(const char *path) {
-    std::ifstream f(path, std::ios::binary | std::ios::ate);
-    std::vector<T> v(static_cast<size_t>(f.tellg()) / sizeof(T));
-    f.seekg(0);
-    f.read(reinterpret_cast<char *>(v.data()), v.size() * sizeof(T));
-    return v;
-}
-int main(int argc, char **argv) {
-    try {
-        mcull::Culler culler(0);
-        culler.loadScene(argv[1]);                                  // kitten.mcs
-        // the reference's own inputs, generated by the library's host code (updateTransforms, createGlobals)
-        const std::vector<mcull::Transform> transforms = mcull::referenceTransforms(1000);
-        const mcull::Globals g = mcull::createGlobals(800, 600, static_cast<uint32_t>(culler.meshletCount()));
-        if (transforms != slurp<mcull::Transform>(argv[2]) || std::memcmp(&g, slurp<mcull::Globals>(argv[3]).data(), sizeof(g)))
-            throw std::runtime_error("generated inputs differ from the committed ones");
-        culler.updateTransforms(transforms);
-        culler.recordFrame(g, 800, 600);
-        auto list = culler.visibleList();
-        auto cmds = culler.indirectCommands();
-        std::printf("visible %llu list %016llx cmds %016llx\n", (unsigned long long)list.size(),
-                    (unsigned long long)fnv(list.data(), list.size() * sizeof(list[0])),
-                    (unsigned long long)fnv(cmds.data(), cmds.size() * sizeof(cmds[0])));
-        // the same frame with the Globals in device memory (the form a captured graph replays)
-        void *g_dev = nullptr;
-        if (hipMalloc(&g_dev, sizeof(g)) != hipSuccess || hipMemcpy(g_dev, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess)
-            throw std::runtime_error("hipMalloc/hipMemcpy failed");
-        culler.recordFrameDeviceGlobals(static_cast<const mcull::Globals *>(g_dev), 800, 600);
-        auto list2 = culler.visibleList();
-        auto cmds2 = culler.indirectCommands();
-        if (fnv(list2.data(), list2.size() * sizeof(list2[0])) != fnv(list.data(), list.size() * sizeof(list[0])) ||
-            fnv(cmds2.data(), cmds2.size() * sizeof(cmds2[0])) != fnv(cmds.data(), cmds.size() * sizeof(cmds[0])))
-            throw std::runtime_error("device-globals frame differs");
-        std::printf("device globals frame equal\n");
-        (void)hipFree(g_dev);
-        // three shards driven by this one thread: every shard's copy of the scene-wide commands equals the
-        // commands of the unsharded cull
-        {
-            mcull_cull_params p{};
-            p.tests = MCULL_TEST_FRUSTUM | MCULL_TEST_CONE;
-            culler.cull(g, &p);
-            auto whole = culler.indirectCommands();
-            const uint64_t want = fnv(whole.data(), whole.size() * sizeof(whole[0]));
-            mcull::MultiGpuCuller multi({0, 0, 0});
-            multi.loadScene(argv[1]);
-            multi.updateTransforms(transforms);
-            multi.cull(g, &p);
-            for (uint32_t r = 0; r < multi.shardCount(); r++) {
-                auto raw = multi.indirectCommands(r);
-                if (raw.size() != whole.size() * sizeof(whole[0]) || fnv(raw.data(), raw.size()) != want)
-                    throw std::runtime_error("sharded commands differ");
-            }
-            if (multi.visibleCounts().back() != culler.visibleCount()) throw std::runtime_error("sharded count differs");
-            std::printf("three shards equal\n");
-        }
-        // the error path behaves like VK_CHECK: message on stderr + std::runtime_error
-        try { culler.loadScene("/nonexistent.mcs"); } catch (const std::runtime_error &e) { std::printf("threw %s\n", e.what()); }
-    } catch (const std::exception &e) {
-        std::printf("FAILED %s\n", e.what());
-        return 1;
-    }
-    return 0;
-}
-"""
+SRC = os.path.join(ROOT, "examples", "engine_frame.cpp")
 
 
 def test_cpp_host_mirror_records_a_frame(tmp_path, mc, O, kitten, config1):
@@ -96,9 +20,8 @@ def test_cpp_host_mirror_records_a_frame(tmp_path, mc, O, kitten, config1):
     mc.save_scene(tmp_path / "kitten.mcs", kitten["vertices"], None, kitten["meshlet_data"], ml)
     t.tofile(tmp_path / "transforms.bin")
     np.ascontiguousarray(g).tofile(tmp_path / "globals.bin")
-    (tmp_path / "frame.cpp").write_text(SRC)
     lib_dir = os.path.dirname(mc.LIB_PATH)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"), str(tmp_path / "frame.cpp"), "-o",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"), SRC, "-o",
                            str(tmp_path / "frame"), "-L", lib_dir, "-lmcull", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(tmp_path / "frame"), str(tmp_path / "kitten.mcs"), str(tmp_path / "transforms.bin"),
                           str(tmp_path / "globals.bin")], capture_output=True, text=True, timeout=120)
@@ -112,4 +35,5 @@ def test_cpp_host_mirror_records_a_frame(tmp_path, mc, O, kitten, config1):
     assert want in out.stdout, (want, out.stdout)
     assert "device globals frame equal" in out.stdout
     assert "three shards equal" in out.stdout
+    assert out.stdout.count("graph frame") == 3
     assert "threw mcull error: MCULL_E_IO" in out.stdout and "mcull error" in out.stderr
