@@ -459,6 +459,14 @@ const char *mcull_group_last_error(const mcull_group *grp);
  * is valid in stream order on shard d's stream and until the next mcull_group_cull. */
 int mcull_group_cull(mcull_group *grp, const mcull_globals *globals, const mcull_cull_params *params,
                      mcull_group_result *results);
+/* The culling work of one recorded frame (Engine::recordCmdBuffer, Engine.cpp:2381-2551) over the shards:
+ * every shard culls with prepass_tests and rasterises its survivors (mcull_depth_rasterize; geometry must be
+ * uploaded on every shard), the shards' depth images are merged on every device into the depth image of the whole
+ * scene (element-wise nearest = maximum, read from the other devices in place), every device builds the pyramid
+ * of slot `view` from it, and mcull_group_cull runs with `params` (NULL: all three tests) against that pyramid.
+ * Results equal the unsharded two-phase frame. */
+int mcull_group_frame(mcull_group *grp, const mcull_globals *globals, uint32_t width, uint32_t height,
+                      uint32_t prepass_tests, uint32_t view, const mcull_cull_params *params, mcull_group_result *results);
 int mcull_group_synchronize(mcull_group *grp);
 /* Synchronous read-back of one device's copy of the scene-wide result; any pointer may be NULL.
  * totals receives n_shards + 1 values. */

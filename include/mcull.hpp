@@ -310,6 +310,15 @@ public:
         stride_ = params && params->cmd_stride ? params->cmd_stride : (params && params->cmd_form == MCULL_CMD_EXT_GROUPS ? 12u : 8u);
         return res;
     }
+    // Engine::recordCmdBuffer's culling work over the shards: cull, depth pre-pass stand-in per shard, the shards'
+    // depth images merged on every device, pyramid, cull with all three tests + the exchange
+    std::vector<mcull_group_result> recordFrame(const Globals &g, uint32_t width, uint32_t height,
+                                                uint32_t prepass_tests = MCULL_TEST_FRUSTUM | MCULL_TEST_CONE, uint32_t view = 0) {
+        std::vector<mcull_group_result> res(shardCount());
+        MCULL_GROUP_CHECK(mcull_group_frame(grp_, &g, width, height, prepass_tests, view, nullptr, res.data()));
+        stride_ = 8;
+        return res;
+    }
     // host copy of the scene-wide command records as device `r` holds them
     std::vector<uint8_t> indirectCommands(uint32_t r) {
         std::vector<uint8_t> raw(instances_ * stride_);

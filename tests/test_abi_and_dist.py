@@ -155,6 +155,15 @@ def _rank_main(rank, world, port, out_dir):
     lst[: r.total] = torch.from_numpy((r.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4")).view("<i4"))
     packed = D.gather_visible_lists(lst, totals_all)
     np.save(os.path.join(out_dir, "packed_%d.npy" % rank), packed.numpy().view("<u4"))
+    # the two-phase frame's exchange: every rank rasterises its own survivors, the images are merged
+    w, h = 320, 240
+    g2 = H.create_globals(width=w, height=h, meshlet_count=len(ml))
+    r1 = O.cull_scene(O.View(g2), t[b:e], ml, tests=3)
+    own = O.rasterize_depth(z["vertices"].view(O.VERTEX), z["meshlet_data"], ml, t[b:e], r1.list, g2, w, h)
+    merged = D.merge_depth(torch.from_numpy(own.copy()))
+    np.save(os.path.join(out_dir, "depth_%d.npy" % rank), merged.numpy())
+    r2 = O.cull_scene(O.View(g2, O.hiz_build(merged.numpy()), w, h), t[b:e], ml, tests=7)
+    np.save(os.path.join(out_dir, "list2_%d.npy" % rank), r2.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -180,6 +189,18 @@ def test_multi_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten, 
     assert np.array_equal(glob, ref.list.view("<u4").reshape(-1, 2))
     for rank in range(world):  # the packed list every rank holds after the optional list gather
         assert np.array_equal(np.load(tmp_path / ("packed_%d.npy" % rank)), glob)
+    # two-phase frame: the merged depth image of every rank is the unsharded image bit for bit, and the shards'
+    # occlusion-tested lists concatenate to the unsharded frame's list
+    w, h = 320, 240
+    g2 = H.create_globals(width=w, height=h, meshlet_count=len(ml))
+    r1 = O.cull_scene(O.View(g2), t, ml, tests=3)
+    img = O.rasterize_depth(kitten["vertices"], kitten["meshlet_data"], ml, t, r1.list, g2, w, h)
+    assert (img > 0).any()
+    for rank in range(world):
+        assert np.load(tmp_path / ("depth_%d.npy" % rank)).view("<u4").tobytes() == img.view("<u4").tobytes()
+    r2 = O.cull_scene(O.View(g2, O.hiz_build(img), w, h), t, ml, tests=7)
+    glob2 = np.concatenate([np.load(tmp_path / ("list2_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(glob2, r2.list.view("<u4").reshape(-1, 2))
 
 
 def test_cpp_wrapper_compiles_and_throws_like_vk_check(tmp_path, mc):

@@ -34,7 +34,7 @@ calls = {
  "mcull_mesh_upload": (None, None), "mcull_mesh_build_meshlets_gpu": (None, None),
  "mcull_mesh_from_arrays_gpu": (None, P, 1, None, 0, None, 0, P, 3, None),
  "mcull_group_destroy": (None,), "mcull_group_size": (None,), "mcull_group_ctx": (None, 0), "mcull_group_cull": (None, P, None, None),
- "mcull_group_synchronize": (None,), "mcull_group_download": (None, 0, None, 0, None, None),
+ "mcull_group_synchronize": (None,), "mcull_group_frame": (None, P, 4, 4, 3, 0, None, None), "mcull_group_download": (None, 0, None, 0, None, None),
  "mcull_mesh_optimize": (None,), "mcull_mesh_build_meshlets": (None,), "mcull_mesh_counts": (None, None), "mcull_mesh_save": (None, b"/tmp/x"),
  "mcull_mesh_vertices": (None,), "mcull_mesh_indices": (None,), "mcull_mesh_meshlet_data": (None,), "mcull_mesh_meshlets": (None,),
  "mcull_create": (0, None, None), "mcull_group_create": (None, 1, None),

@@ -97,3 +97,38 @@ def test_group_rejects_what_it_cannot_rebase(mc, kitten, config1):
         mc.Group([])
     with pytest.raises(mc.McullError):
         mc.Group([99])
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_group_two_phase_frame_equals_the_unsharded_frame(mc, O, kitten, config1, shards):
+    """cull -> rasterise per shard -> merged depth -> pyramid -> cull with occlusion: the merged depth image
+    (level 0 of every device's pyramid), the scene-wide commands and the concatenated lists equal the oracle's
+    two-phase frame of the unsharded scene, on two frames in a row with different cameras."""
+    t = config1["transforms"]
+    ml, md, vt = kitten["meshlets"], kitten["meshlet_data"], kitten["vertices"]
+    w, h = 800, 600
+    cuts = _cuts(len(t), shards)
+    with mc.Group([0] * shards) as grp:
+        for r, s in enumerate(grp.shards):
+            s.upload_meshlets(ml)
+            s.upload_geometry(vt, md)
+            s.upload_transforms(t[cuts[r]:cuts[r + 1]])
+        for eye in (None, (3.0, 1.5, 2.5)):
+            g = mc.create_globals(w, h, len(ml), eye=eye)
+            r1 = O.cull_scene(O.View(g), t, ml, tests=3)
+            img = O.rasterize_depth(vt, md, ml, t, r1.list, g, w, h)
+            r2 = O.cull_scene(O.View(g, O.hiz_build(img), w, h), t, ml, tests=7)
+            assert 0 < r2.total <= r1.total
+            grp.frame(g, w, h)
+            lists = []
+            for r, s in enumerate(grp.shards):
+                assert s.hiz_download(view=0)[0].view("<u4").tobytes() == img.view("<u4").tobytes()
+                raw, _, totals = grp.download(r)
+                cmds = raw.view(mc.CMD).reshape(-1)
+                assert int(totals[-1]) == r2.total
+                assert np.array_equal(cmds["taskCount"], r2.commands["taskCount"])
+                assert np.array_equal(cmds["firstTask"], r2.commands["firstTask"])
+                lst = s.download_list().copy()
+                lst["drawID"] += cuts[r]
+                lists.append(lst)
+            assert np.concatenate(lists).tobytes() == r2.list.tobytes()

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
     "mcull_cull_views_device_globals",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
-    "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download",
+    "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
 ]
 GROUP_MAX_SHARDS = 64
 
@@ -162,6 +162,7 @@ _sig("mcull_group_size", _U32, [_P])
 _sig("mcull_group_ctx", _P, [_P, _U32])
 _sig("mcull_group_last_error", C.c_char_p, [_P])
 _sig("mcull_group_cull", _I, [_P, _P, C.POINTER(CullParams), _P])
+_sig("mcull_group_frame", _I, [_P, _P, _U32, _U32, _U32, _U32, C.POINTER(CullParams), _P])
 _sig("mcull_group_synchronize", _I, [_P])
 _sig("mcull_group_download", _I, [_P, _U32, _P, _U64, _P, _P])
 
@@ -648,6 +649,24 @@ class Group:
         n = len(self.shards)
         R = (GroupResult * n)()
         self._chk(lib.mcull_group_cull(self._h, _np_ptr(g), C.byref(p), C.cast(R, _P)))
+        self._stride = cmd_stride or (12 if cmd_form == CMD_EXT_GROUPS else 8)
+        self._ext = cmd_form == CMD_EXT_GROUPS
+        self._n_instances = int(R[0].n_instances)
+        for s, r in zip(self.shards, R):
+            s._last = (int(r.local.n_groups), int(r.local.n_pairs), cmd_stride)
+        return list(R)
+
+    def frame(self, globals_, width, height, prepass_tests=TEST_FRUSTUM | TEST_CONE, view=0, tests=TEST_ALL,
+              cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0):
+        """The two-phase frame over the shards: cull, rasterise, merge the depth images, pyramid, cull + exchange."""
+        g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
+        p = CullParams(tests, COMPACT_ORDERED, view, cmd_form, cmd_stride, cmd_offset, 0, 0, None, 0, None, None)
+        n = len(self.shards)
+        R = (GroupResult * n)()
+        self._chk(lib.mcull_group_frame(self._h, _np_ptr(g), width, height, prepass_tests, view, C.byref(p), C.cast(R, _P)))
+        for s in self.shards:  # every shard now holds the scene's pyramid in that slot
+            s._hiz_dims = getattr(s, "_hiz_dims", {})
+            s._hiz_dims[view] = (width, height)
         self._stride = cmd_stride or (12 if cmd_form == CMD_EXT_GROUPS else 8)
         self._ext = cmd_form == CMD_EXT_GROUPS
         self._n_instances = int(R[0].n_instances)

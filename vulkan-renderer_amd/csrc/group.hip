@@ -78,6 +78,32 @@ __global__ void group_push_kernel(const uint4 *__restrict__ block, uint64_t n_ve
         dst[i] = block[i];
 }
 
+// The shards' depth images of one frame (each holds only its own instances) merged into the depth image of the
+// whole scene: reverse-Z, larger = nearer, and a rasterised depth is a non-negative float, so the nearest
+// surface is the maximum of the bit patterns - the same merge the rasteriser's atomicMax performs inside a shard.
+struct DepthSources {
+    uint32_t n;
+    const uint32_t *src[kMaxShards];
+};
+
+__global__ void group_depth_max_kernel(uint32_t *__restrict__ dst, DepthSources s, uint64_t n_words) {
+    const uint64_t n_vec = n_words / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = tid; i < n_vec; i += stride) {
+        uint4 m = reinterpret_cast<const uint4 *>(s.src[0])[i];
+        for (uint32_t r = 1; r < s.n; r++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(s.src[r])[i];
+            m.x = max(m.x, v.x); m.y = max(m.y, v.y); m.z = max(m.z, v.z); m.w = max(m.w, v.w);
+        }
+        reinterpret_cast<uint4 *>(dst)[i] = m;
+    }
+    for (uint64_t i = n_vec * 4 + tid; i < n_words; i += stride) {
+        uint32_t m = s.src[0][i];
+        for (uint32_t r = 1; r < s.n; r++) m = max(m, s.src[r][i]);
+        dst[i] = m;
+    }
+}
+
 struct Buf {
     void *p = nullptr;
     size_t cap = 0;
@@ -92,7 +118,8 @@ struct mcull_group {
         int device = 0;
         hipStream_t stream = nullptr;
         mcull_ctx *ctx = nullptr;
-        hipEvent_t pushed = nullptr;
+        hipEvent_t pushed = nullptr, step = nullptr;  // step: this shard's rasteriser / merge of mcull_group_frame is done
+        Buf merged, peer_depth;                       // the scene's depth image; copies of the other shards' images (no peer access)
         // blocks are received into staged[frame & 1]: a frame's blocks never land in the buffer the previous
         // frame's packing kernel may still be reading, and the one before that is done on every device by the
         // time anybody sends again (each sender has by then waited for all blocks of the frame in between)
@@ -104,7 +131,8 @@ struct mcull_group {
     // the n-to-n "all blocks have arrived" dependency goes through one stream: it waits for every shard's
     // push, records `arrived`, and every shard waits for that one event (2n stream waits per frame, not n*n)
     hipStream_t join = nullptr;
-    hipEvent_t arrived = nullptr;
+    hipEvent_t arrived = nullptr, all_merged = nullptr;
+    bool merged_recorded = false;
     int join_device = 0;
     bool direct = true;   // every pair of devices can store into each other's memory: one push kernel per shard
     uint64_t frame = 0;
@@ -174,6 +202,7 @@ int mcull_group_create(const int *device_ordinals, uint32_t n_shards, mcull_grou
         bool ok = hipSetDevice(s.device) == hipSuccess &&
                   hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&s.pushed, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&s.step, hipEventDisableTiming) == hipSuccess &&
                   mcull_create(s.device, s.stream, &s.ctx) == MCULL_OK;
         if (!ok) {
             mcull_group_destroy(g);
@@ -198,7 +227,8 @@ int mcull_group_create(const int *device_ordinals, uint32_t n_shards, mcull_grou
     }
     g->join_device = device_ordinals[0];
     if (hipSetDevice(g->join_device) != hipSuccess || hipStreamCreateWithFlags(&g->join, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&g->arrived, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&g->arrived, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->all_merged, hipEventDisableTiming) != hipSuccess) {
         mcull_group_destroy(g);
         return MCULL_E_HIP;
     }
@@ -220,14 +250,16 @@ int mcull_group_destroy(mcull_group *g) {
         mcull_group::Shard &s = g->shard[r];
         (void)hipSetDevice(s.device);
         if (s.ctx) (void)mcull_destroy(s.ctx);
-        for (Buf *b : {&s.send, &s.staged[0], &s.staged[1], &s.commands, &s.first_task, &s.totals})
+        for (Buf *b : {&s.send, &s.staged[0], &s.staged[1], &s.commands, &s.first_task, &s.totals, &s.merged, &s.peer_depth})
             if (b->p) (void)hipFree(b->p);
         if (s.pushed) (void)hipEventDestroy(s.pushed);
+        if (s.step) (void)hipEventDestroy(s.step);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     (void)hipSetDevice(g->join_device);
     if (g->join) (void)hipStreamSynchronize(g->join);
     if (g->arrived) (void)hipEventDestroy(g->arrived);
+    if (g->all_merged) (void)hipEventDestroy(g->all_merged);
     if (g->join) (void)hipStreamDestroy(g->join);
     delete g;
     return MCULL_OK;
@@ -368,6 +400,90 @@ int mcull_group_cull(mcull_group *g, const mcull_globals *globals, const mcull_c
     g->have_result = true;
     g->frame++;
     return MCULL_OK;
+}
+
+
+int mcull_group_frame(mcull_group *g, const mcull_globals *globals, uint32_t width, uint32_t height, uint32_t prepass_tests,
+                      uint32_t view, const mcull_cull_params *params, mcull_group_result *results) {
+    if (!g) return MCULL_E_INVALID;
+    if (!globals) return gfail(g, MCULL_E_INVALID, "globals is null");
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return gfail(g, MCULL_E_INVALID, "depth size %ux%u", width, height);
+    if (view >= MCULL_MAX_VIEWS) return gfail(g, MCULL_E_INVALID, "view slot %u out of range", view);
+    const uint64_t n_words = (uint64_t)width * height;
+    // buffers first (growing one drains the whole group)
+    bool regrow = false;
+    for (uint32_t r = 0; r < g->n; r++)
+        regrow |= too_small(g->shard[r].merged, n_words * 4) || (!g->direct && too_small(g->shard[r].peer_depth, n_words * 4 * g->n));
+    if (regrow)
+        if (int rc = mcull_group_synchronize(g)) return rc;
+    for (uint32_t r = 0; r < g->n; r++) {
+        mcull_group::Shard &s = g->shard[r];
+        GHIP(g, hipSetDevice(s.device));
+        if (int rc = grow(g, s.merged, n_words * 4, s.stream)) return rc;
+        if (!g->direct)
+            if (int rc = grow(g, s.peer_depth, n_words * 4 * g->n, s.stream)) return rc;
+    }
+    // phase 1 on every shard: cull without history, rasterise the survivors into the shard's own depth image.
+    // The image is cleared first, so the other devices must be done reading the last frame's.
+    const uint32_t *own_depth[kMaxShards];
+    mcull_cull_params pre;
+    std::memset(&pre, 0, sizeof pre);
+    pre.tests = prepass_tests;
+    pre.hiz_view = view;
+    for (uint32_t r = 0; r < g->n; r++) {
+        mcull_group::Shard &s = g->shard[r];
+        GHIP(g, hipSetDevice(s.device));
+        if (g->n > 1 && g->merged_recorded) GHIP(g, hipStreamWaitEvent(s.stream, g->all_merged, 0));
+        if (int rc = mcull_cull(s.ctx, globals, &pre, nullptr)) return gfail(g, rc, "shard %u: %s", r, mcull_last_error(s.ctx));
+        if (int rc = mcull_depth_rasterize(s.ctx, globals, width, height, 1)) return gfail(g, rc, "shard %u: %s", r, mcull_last_error(s.ctx));
+        const float *d = nullptr;
+        if (int rc = mcull_depth_buffer(s.ctx, &d, nullptr, nullptr)) return gfail(g, rc, "shard %u: %s", r, mcull_last_error(s.ctx));
+        own_depth[r] = reinterpret_cast<const uint32_t *>(d);
+        GHIP(g, hipEventRecord(s.step, s.stream));
+    }
+    if (g->n > 1) {
+        GHIP(g, hipSetDevice(g->join_device));
+        for (uint32_t r = 0; r < g->n; r++) GHIP(g, hipStreamWaitEvent(g->join, g->shard[r].step, 0));
+        GHIP(g, hipEventRecord(g->arrived, g->join));
+    }
+    // every device merges all shards' images (read in place over the links, or copied first) and builds the pyramid
+    for (uint32_t d = 0; d < g->n; d++) {
+        mcull_group::Shard &t = g->shard[d];
+        GHIP(g, hipSetDevice(t.device));
+        if (g->n > 1) GHIP(g, hipStreamWaitEvent(t.stream, g->arrived, 0));
+        DepthSources ds;
+        ds.n = g->n;
+        for (uint32_t r = 0; r < g->n; r++) {
+            ds.src[r] = own_depth[r];
+            if (!g->direct && g->shard[r].device != t.device) {
+                uint32_t *copy = (uint32_t *)t.peer_depth.p + (uint64_t)r * n_words;
+                GHIP(g, hipMemcpyPeerAsync(copy, t.device, own_depth[r], g->shard[r].device, n_words * 4, t.stream));
+                ds.src[r] = copy;
+            }
+        }
+        const uint32_t threads = 256;
+        uint64_t blocks = (n_words / 4 + threads - 1) / threads;
+        if (blocks == 0) blocks = 1;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(group_depth_max_kernel, dim3((uint32_t)blocks), dim3(threads), 0, t.stream, (uint32_t *)t.merged.p, ds, n_words);
+        GHIP(g, hipGetLastError());
+        GHIP(g, hipEventRecord(t.step, t.stream));
+        if (int rc = mcull_hiz_build(t.ctx, view, (const float *)t.merged.p, width, height, MCULL_MEM_DEVICE))
+            return gfail(g, rc, "shard %u: %s", d, mcull_last_error(t.ctx));
+    }
+    if (g->n > 1) {
+        GHIP(g, hipSetDevice(g->join_device));
+        for (uint32_t r = 0; r < g->n; r++) GHIP(g, hipStreamWaitEvent(g->join, g->shard[r].step, 0));
+        GHIP(g, hipEventRecord(g->all_merged, g->join));
+        g->merged_recorded = true;
+    }
+    // phase 2: the cull with occlusion against the scene's pyramid, and the exchange
+    mcull_cull_params p;
+    std::memset(&p, 0, sizeof p);
+    if (params) p = *params;
+    else p.tests = MCULL_TEST_ALL;
+    p.hiz_view = view;
+    return mcull_group_cull(g, globals, &p, results);
 }
 
 int mcull_group_synchronize(mcull_group *g) {

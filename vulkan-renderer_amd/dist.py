@@ -6,6 +6,11 @@ shard, and two small all-gathers turn the per-rank results into one global draw 
      (on the device for the GPU path: mcull_rebase_commands reads the gathered counts);
   3. all-gather of the per-instance indirect commands.
 
+The two-phase frame (cull, depth pre-pass, pyramid, cull with occlusion) adds one exchange: every rank
+rasterises only its own instances, so the ranks' depth images are merged with an all-reduce (maximum:
+reverse-Z, larger = nearer) before each rank builds the pyramid of the whole scene (merge_depth,
+sharded_frame).
+
 The reference is single-GPU (Engine.cpp:658-666 picks one device); this has no counterpart there.
 torch.distributed is the transport ("nccl" is RCCL on ROCm, "gloo" on CPU for tests).
 """
@@ -92,3 +97,36 @@ def gather_draw_list_packed(cmds_packed, group=None):
     cmds_all = g[:, : rows - 1, :]
     cmds_all[:, :, 1] += base.to(torch.int32)[:, None]  # firstTask wraps modulo 2^32 like the 32-bit field it is
     return totals_all, cmds_all
+
+
+def merge_depth(depth, group=None):
+    """In place: the element-wise maximum over all ranks of `depth` (float32 tensor, the rank's own
+    rasterised image, 0 where it drew nothing).  Depth is reverse-Z and never negative or NaN, so the maximum
+    is the nearest surface of any rank - the merge the rasteriser's atomicMax performs inside a rank - and the
+    result does not depend on the order of the reduction: it equals the unsharded image bit for bit."""
+    dist.all_reduce(depth, op=dist.ReduceOp.MAX, group=group)
+    return depth
+
+
+class _DeviceArray:
+    """A device buffer owned by the library, described for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def sharded_frame(ctx, stream, globals_, width, height, view=0, prepass_tests=3, group=None, **cull_kwargs):
+    """The culling work of one recorded frame (Engine.cpp:2381-2551) on a rank that holds one shard of the
+    instances: cull with `prepass_tests`, rasterise the survivors, merge the depth images of all ranks
+    (one all-reduce of width*height floats), build the pyramid of the whole scene in slot `view`, cull with
+    all three tests (cull_kwargs are passed on to ctx.cull).  `stream` is the torch.cuda.Stream the context
+    was created on: the collective is issued on it, between the rasteriser and the pyramid.  Returns the
+    result of the second cull; gather_draw_list / gather_draw_list_packed then describe the global list."""
+    ctx.cull(globals_, tests=prepass_tests, hiz_view=view)
+    ctx.depth_rasterize(globals_, width, height)
+    ptr, w, h = ctx.depth_buffer()
+    depth = torch.as_tensor(_DeviceArray(ptr, (h, w), "<f4"), device="cuda:%d" % ctx.device)
+    with torch.cuda.stream(stream):
+        merge_depth(depth, group=group)
+    ctx.hiz_build(ptr, view=view, width=width, height=height, mem=1)
+    return ctx.cull(globals_, hiz_view=view, **cull_kwargs)
