@@ -213,6 +213,26 @@ def roofline(algo_bytes, kernel_ms, kernel_name, traffic=None, traffic_src=None,
     return r
 
 
+def measured_copy_gbs(device, mib=1024, reps=10):
+    """The device-to-device copy rate of this GPU, measured now (read + write bytes per second of a 1 GiB
+    hipMemcpy): the ceiling a plain copy reaches on this box, reported next to the 8 TB/s datasheet peak."""
+    n = mib << 20
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    return round(2.0 * n / (ms * 1e-3) / 1e9, 1)
+
+
 def host_threads():
     import oracle as O
 
@@ -413,6 +433,9 @@ def run_cull(env, workload):
         out["roofline"] = roofline(algo, k_ms, kernels, traffic, traffic_src,
                                    kernel_ms_single_call=round(float(np.mean(kernel_ms)), 4),
                                    bytes_per_pair=round(algo / (n_pairs * n_views), 2))
+        if world == 1:
+            out["roofline"]["measured_device_copy"] = measured_copy_gbs(device)
+            out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / out["roofline"]["measured_device_copy"], 4)
         if with_lists:
             out["with_list_gather"] = with_lists
         if not args.no_cpu_baseline and world == 1:
