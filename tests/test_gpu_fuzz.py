@@ -186,3 +186,60 @@ def test_random_pyramids(mc, O, hiz_contexts, seed):
             assert len(got) == len(ref)
             for lvl, (a, b) in enumerate(zip(got, ref)):
                 assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "seed %d %dx%d level %d" % (seed, w, h, lvl)
+
+
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
+def test_random_groups(mc, O, H, seed):
+    """Random shard counts and cut points (empty shards included), ranged or uniform scenes, NV and EXT records at
+    random strides, several frames per group: every device's scene-wide buffers against the oracle's unsharded cull."""
+    rs = np.random.RandomState(7000 + seed)
+    shards = int(rs.choice([1, 2, 3, 5, 8]))
+    n_meshlets = int(rs.choice([1, 64, 65, 300, 2000]))
+    n_inst = int(rs.choice([1, 5, 64, 300]))
+    cone, sphere = H.synthetic_bounds(n_meshlets, seed=seed)
+    sphere = sphere.copy()
+    sphere[:, :3] = (sphere[:, :3] - 0.5) * rs.uniform(0.5, 4.0)
+    t = H.synthetic_transforms(n_inst, extent=float(rs.uniform(2.0, 30.0)), seed=seed + 1)
+    ranged = rs.rand() < 0.6
+    if ranged:
+        off = rs.randint(0, n_meshlets, n_inst).astype("<u4")
+        cnt = np.minimum(rs.randint(0, min(n_meshlets, 200) + 1, n_inst), n_meshlets - off).astype("<u4")
+        cnt[rs.rand(n_inst) < 0.2] = 0
+    cuts = np.sort(rs.randint(0, n_inst + 1, shards - 1)).tolist()
+    cuts = [0] + cuts + [n_inst]
+    w, h = int(rs.choice([64, 257, 640])), int(rs.choice([48, 128, 360]))
+    depth = H.synthetic_depth(w, h, n_discs=int(rs.randint(1, 20)), seed=seed + 2)
+    pyr = O.hiz_build(depth)
+    with mc.Group([0] * shards) as grp:
+        for r, s in enumerate(grp.shards):
+            s.upload_bounds_soa(cone, sphere)
+            s.upload_transforms(t[cuts[r]:cuts[r + 1]])
+            if ranged:
+                s.set_instance_ranges(off[cuts[r]:cuts[r + 1]], cnt[cuts[r]:cuts[r + 1]])
+            s.hiz_build(depth, view=2)
+        for _ in range(3):
+            g = H.create_globals(eye=tuple(rs.uniform(-25, 25, 3)), centre=tuple(rs.uniform(-5, 5, 3)), fov_deg=float(rs.uniform(20, 100)),
+                                 width=w, height=h, flip_y=bool(rs.rand() < 0.5), meshlet_count=n_meshlets)
+            tests = int(rs.randint(0, 8))
+            ext = bool(rs.rand() < 0.4)
+            stride, offset = [(0, 0), (28, 16 if ext else 20), (16, 4)][int(rs.randint(0, 3))]
+            ref = O.cull_scene(O.View(g, pyr, w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt) if ranged else None, tests=tests)
+            grp.cull(g, tests=tests, hiz_view=2, cmd_form=mc.CMD_EXT_GROUPS if ext else mc.CMD_NV_MESHLETS, cmd_stride=stride, cmd_offset=offset)
+            rec = 12 if ext else 8
+            st = stride or rec
+            own = np.where(cnt > 0)[0] if ranged else np.arange(n_inst if n_meshlets else 0)
+            lists = []
+            for r, s in enumerate(grp.shards):
+                raw, ft, totals = grp.download(r)
+                assert int(totals[-1]) == ref.total, (seed, r)
+                words = raw.reshape(n_inst, st)[:, offset:offset + rec].copy().view("<u4").reshape(n_inst, rec // 4)
+                assert np.array_equal(words[:, 0], ref.commands["taskCount"])
+                if ext:
+                    assert (words[:, 1:] == 1).all()
+                    assert np.array_equal(ft[own], ref.commands["firstTask"][own])
+                else:
+                    assert np.array_equal(words[own, 1], ref.commands["firstTask"][own])
+                lst = s.download_list().copy()
+                lst["drawID"] += cuts[r]
+                lists.append(lst)
+            assert np.concatenate(lists).tobytes() == ref.list.tobytes()
