@@ -117,6 +117,13 @@ def test_random_triangles_through_the_rasteriser(mc, O, H, contexts, seed):
     ctx.upload_meshlets(meshlets)
     ctx.upload_geometry(verts, data)
     ctx.compute_bounds()
+    # cone, apex and radius of these random (partly degenerate) meshlets against buildMeshletCon; where an invalid
+    # operation made a NaN its sign and payload follow the machine, so NaNs compare alike
+    got_b, want_b = ctx.download_meshlets(len(meshlets)), O.build_meshlet_cones(verts, data, meshlets)
+    for f in ("cone", "coneApex", "radius"):
+        a, b = np.asarray(got_b[f], dtype="<f4"), np.asarray(want_b[f], dtype="<f4")
+        same = (a.view("<u4") == b.view("<u4")) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (seed, f)
     ctx.upload_transforms(t)
     ctx.cull(g, tests=0)  # every pair: the rasteriser has to cope with what a cull would have removed
     lst = ctx.download_list()
@@ -243,3 +250,54 @@ def test_random_groups(mc, O, H, seed):
                 lst["drawID"] += cuts[r]
                 lists.append(lst)
             assert np.concatenate(lists).tobytes() == ref.list.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
+def test_random_views_and_payloads(mc, O, H, contexts, seed):
+    """1-8 views with their own cameras, tests and pyramids in one pass, the Globals handed over from the host and
+    from a device array; every view equals its own single cull.  Then the literal per-32 task payloads of one view."""
+    import torch
+
+    rs = np.random.RandomState(11000 + seed)
+    ctx = contexts[seed & 1]
+    n_views = int(rs.randint(1, mc.MAX_VIEWS + 1))
+    n_meshlets = int(rs.choice([1, 33, 64, 97, 500]))
+    n_inst = int(rs.choice([1, 3, 70, 400]))
+    cone, sphere = H.synthetic_bounds(n_meshlets, seed=seed + 5)
+    sphere = sphere.copy()
+    sphere[:, :3] = (sphere[:, :3] - 0.5) * rs.uniform(0.5, 4.0)
+    t = H.synthetic_transforms(n_inst, extent=float(rs.uniform(2.0, 25.0)), seed=seed + 6)
+    ml = np.zeros(n_meshlets, dtype=mc.MESHLET)  # AoS upload: payloads and multi-view use the same records
+    ml["cone"], ml["coneApex"][:, :3], ml["radius"] = cone, sphere[:, :3], sphere[:, 3]
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(ml)
+    ctx.upload_transforms(t)
+    views, params, refs = [], [], []
+    for v in range(n_views):
+        w, h = int(rs.choice([64, 200, 640])), int(rs.choice([48, 150, 360]))
+        depth = H.synthetic_depth(w, h, n_discs=int(rs.randint(1, 16)), seed=seed * 10 + v)
+        ctx.hiz_build(depth, view=v)
+        g = H.create_globals(eye=tuple(rs.uniform(-20, 20, 3)), centre=tuple(rs.uniform(-4, 4, 3)), fov_deg=float(rs.uniform(25, 95)),
+                             width=w, height=h, flip_y=bool(rs.rand() < 0.5), meshlet_count=n_meshlets)
+        tests = int(rs.randint(0, 8))
+        views.append(g)
+        params.append(dict(tests=tests, hiz_view=v, write_mask=True))
+        refs.append(O.cull_scene(O.View(g, O.hiz_build(depth), w, h), t, ml, tests=tests))
+    packed = np.concatenate([np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1) for g in views])
+    g_dev = torch.from_numpy(packed.view("u1").reshape(-1).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    for device_globals in (False, True):
+        if device_globals:
+            ctx.cull_views(n_views, params, device_globals_ptr=g_dev.data_ptr(), meshlet_count=n_meshlets)
+        else:
+            ctx.cull_views(views, params)
+        for v in range(n_views):
+            ctx.select_result(v)
+            assert np.array_equal(ctx.download_mask(), refs[v].mask), (seed, v, device_globals)
+            check_against_oracle(mc, ctx, refs[v], n_inst, 0)
+    v = int(rs.randint(0, n_views))
+    ctx.select_result(v)
+    want = O.task_payloads(O.View(views[v]), t, ml, tests=params[v]["tests"] & 3)  # frustum / cone only: no pyramid involved
+    ctx.cull(views[v], tests=params[v]["tests"] & 3)
+    assert ctx.task_payloads().tobytes() == want.tobytes()
+
