@@ -228,3 +228,43 @@ int main() {
         assert "created" in out.stdout
     else:
         assert "threw mcull error: MCULL_E_HIP" in out.stdout and "mcull error" in out.stderr
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path, mc):
+    """include/mcull.h from a C99 translation unit (the boundary is a C ABI, not a C++ one): the layout contract
+    holds under the C compiler too, the host-only entry points work, and without a GPU mcull_create reports
+    MCULL_E_HIP instead of computing anything."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "mcull.h"
+_Static_assert(sizeof(mcull_meshlet) == 48 && sizeof(mcull_globals) == 212 && sizeof(mcull_transform) == 64, "layout");
+_Static_assert(sizeof(mcull_draw_indirect) == 28 && offsetof(mcull_draw_indirect, commandMeshIndirect) == 20, "DrawIndirect");
+_Static_assert(sizeof(mcull_visible) == 8 && sizeof(mcull_task_payload) == 136 && sizeof(mcull_vertex) == 24, "layout");
+int main(void) {
+    mcull_globals g;
+    mcull_transform t[3];
+    mcull_draw_indirect d[3];
+    if (mcull_create_globals(NULL, NULL, NULL, 45.0f, 0.1f, 800, 600, 1, 326, &g) != MCULL_OK) return 1;
+    if (mcull_reference_transforms(3, 42, t) != MCULL_OK || mcull_create_indirect_buffer(3, 326, 86832, d) != MCULL_OK) return 2;
+    if (g.meshletCount != 326 || d[2].commandMeshIndirect.taskCount != 11 || d[2].commandMeshIndirect.firstTask != 0) return 3;
+    mcull_ctx *ctx = NULL;
+    int rc = mcull_create(0, NULL, &ctx);
+    printf("version %d levels %u create %s\n", mcull_version(), mcull_hiz_level_count(800, 600), mcull_status_string(rc));
+    if (ctx) mcull_destroy(ctx);
+    return 0;
+}
+''')
+    lib_dir = os.path.dirname(mc.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-lmcull", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "levels 10" in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "create MCULL_E_HIP" in out.stdout
