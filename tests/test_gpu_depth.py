@@ -282,3 +282,55 @@ def test_adversarial_vertices(mc, O, ctx, kitten, H):
     got = ctx.depth_download()
     assert np.array_equal(_bits(got), _bits(want))
     assert (want > 0).any() and not np.isnan(want).any()
+
+
+def test_captured_multi_view_cull_follows_moving_cameras(mc, O, H, kitten, config1):
+    """mcull_cull_views_device_globals captured once: three views per replay, their Globals refreshed in the
+    device array between replays; each view of each replay equals the oracle's cull for that camera."""
+    import torch
+
+    t = config1["transforms"][:200]
+    ml = kitten["meshlets"]
+    w, h, nv = 320, 240, 3
+    stream = torch.cuda.Stream()
+    c = mc.Context(0, stream=stream.cuda_stream)
+    c.upload_meshlets(ml)
+    c.upload_transforms(t)
+    pyrs = []
+    for v in range(nv):
+        depth = H.synthetic_depth(w, h, n_discs=10, seed=30 + v)
+        c.hiz_build(depth, view=v)
+        pyrs.append(O.hiz_build(depth))
+    params = [dict(tests=7, hiz_view=v, write_mask=True) for v in range(nv)]
+
+    def cameras(frame):
+        return [H.create_globals(eye=(6.0 * np.cos(0.7 * frame + v), 6.0 * np.sin(0.7 * frame + v), 2.0 + v), fov_deg=50.0, width=w,
+                                 height=h, flip_y=bool(v & 1), meshlet_count=len(ml)) for v in range(nv)]
+
+    def stage(views):
+        packed = np.concatenate([np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1) for g in views])
+        return torch.from_numpy(packed.view("u1").reshape(-1).copy()).cuda()
+
+    g_dev = torch.zeros(nv * 212, dtype=torch.uint8, device="cuda")
+    staged = [stage(cameras(f)) for f in range(3)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        g_dev.copy_(staged[0])
+    c.cull_views(nv, params, device_globals_ptr=g_dev.data_ptr(), meshlet_count=len(ml))  # the allocating run
+    c.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        c.cull_views(nv, params, device_globals_ptr=g_dev.data_ptr(), meshlet_count=len(ml))
+    for f in (1, 2, 0):
+        with torch.cuda.stream(stream):
+            g_dev.copy_(staged[f])
+        stream.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        for v, g in enumerate(cameras(f)):
+            ref = O.cull_scene(O.View(g, pyrs[v], w, h), t, ml, tests=7)
+            c.select_result(v)
+            assert c.download_count() == ref.total, (f, v)
+            assert c.download_list().tobytes() == ref.list.tobytes(), (f, v)
+            assert np.array_equal(c.download_mask(), ref.mask), (f, v)
+    c.close()
