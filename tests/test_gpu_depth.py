@@ -334,3 +334,61 @@ def test_captured_multi_view_cull_follows_moving_cameras(mc, O, H, kitten, confi
             assert c.download_list().tobytes() == ref.list.tobytes(), (f, v)
             assert np.array_equal(c.download_mask(), ref.mask), (f, v)
     c.close()
+
+
+def _screen_filling_scene(mc, rs, n_quads):
+    """Quads far larger than the screen, at different depths and tilts, both windings (one of each pair faces the camera)."""
+    verts = np.zeros(4 * n_quads, dtype=mc.VERTEX)
+    meshlets = np.zeros(n_quads, dtype=mc.MESHLET)
+    data = []
+    for q in range(n_quads):
+        z = rs.uniform(-3.0, 1.0)
+        tilt = rs.uniform(-0.02, 0.02, 4)
+        verts["pos"][4 * q:4 * q + 4, :3] = [[-40, -40, z + tilt[0] * 40], [40, -40, z + tilt[1] * 40], [40, 40, z + tilt[2] * 40], [-40, 40, z + tilt[3] * 40]]
+        meshlets[q]["dataOffset"] = sum(len(x) for x in data)
+        meshlets[q]["vertexCount"], meshlets[q]["triangleCount"] = 4, 4
+        data += [np.arange(4 * q, 4 * q + 4, dtype="<u4"), np.array([0, 1, 2, 0, 2, 3, 0, 2, 1, 0, 3, 2], dtype="u1").view("<u4")]
+    return verts, meshlets, np.concatenate(data).astype("<u4")
+
+
+@pytest.mark.parametrize("queue", [None, "3,40", "1,1", "0,0", "1000,7"])
+def test_huge_triangles_go_through_the_job_queue(mc, O, monkeypatch, queue):
+    """Boxes above 128x128 pixels are cut into pieces for a second kernel.  Same image as the oracle's, with the
+    default queue and with queues so small that some or all of the triangles are walked in place instead."""
+    if queue is not None:
+        monkeypatch.setenv("MCULL_RASTER_QUEUE", queue)
+    import subprocess, sys, os, textwrap
+
+    # the queue size is read once per process: every setting runs in a process of its own
+    code = textwrap.dedent('''
+        import importlib, sys
+        import numpy as np
+        sys.path.insert(0, sys.argv[1])
+        sys.path.insert(0, sys.argv[1] + "/tests")
+        mc = importlib.import_module("vulkan-renderer_amd")
+        import oracle as O
+        from test_gpu_depth import _screen_filling_scene
+        rs = np.random.RandomState(3)
+        verts, meshlets, data = _screen_filling_scene(mc, rs, 6)
+        t = np.zeros(2, dtype=mc.TRANSFORM)
+        t["model"][0] = np.eye(4, dtype="<f4").reshape(-1)
+        m = np.eye(4, dtype="<f4"); m[3, :3] = [3.0, -2.0, 0.5]; t["model"][1] = m.reshape(-1)
+        with mc.Context(0) as ctx:
+            ctx.upload_meshlets(meshlets)
+            ctx.upload_geometry(verts, data)
+            ctx.compute_bounds()
+            ctx.upload_transforms(t)
+            for (w, h), eye in (((800, 600), (0.0, 0.0, 5.0)), ((333, 517), (1.0, 2.0, 4.0)), ((1024, 1024), (0.0, 0.5, 2.0))):
+                g = mc.create_globals(w, h, len(meshlets), eye=eye, up=(0.0, 1.0, 0.0))
+                for rep in range(2):  # the second call starts from the counters the first one left
+                    ctx.cull(g, tests=0)
+                    ctx.depth_rasterize(g, w, h)
+                    got = ctx.depth_download()
+                want = O.rasterize_depth(verts, data, meshlets, t, ctx.download_list(), g, w, h)
+                assert (want > 0).mean() > 0.9
+                assert np.array_equal(got.view("<u4"), want.view("<u4")), (w, h, int((got.view("<u4") != want.view("<u4")).sum()))
+        print("huge ok")
+    ''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0 and "huge ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -29,6 +29,35 @@ constexpr int kRasterBlock = 256;
 // reference's scene at 800x600 (triangles of tens of pixels) 8 costs 114 us against 77 us for 32, and 128 gains nothing
 constexpr uint32_t kSmallBox = 32;
 
+// A box above kHugeBox pixels is not walked by the wave that found it: the triangle goes into a table and its
+// box, cut into kJobTile x kJobTile pixel pieces, into a job queue that a second kernel spreads over the whole
+// device (one wave per piece).  Without it a single screen-filling quad keeps ONE wave busy for 35 ms at
+// 3840x2160 (2 ms at 800x600, 284 ms at 8192^2) while the rest of the device idles.  Same expressions on
+// the same screen-space values, merged by the same atomic maximum: the image does not change.
+constexpr uint32_t kHugeBox = 128u * 128u;
+constexpr uint32_t kJobTile = 64u;
+constexpr uint32_t kQueueTriangles = 1u << 16;   // 3 MB of triangle records
+constexpr uint32_t kQueueJobs = 1u << 20;        // 8 MB of jobs; what does not fit is walked in place as before
+
+struct HugeTri {       // 48 bytes
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    uint32_t origin;   // box origin  x | y << 16
+    uint32_t extent;   // box extent  (w - 1) | (h - 1) << 16
+    uint32_t pad;
+};
+struct HugeJob {
+    uint32_t tri;      // index into the triangle table, 0xffffffff = nothing to do
+    uint32_t piece;    // piece of the box  x | y << 16, in units of kJobTile
+};
+// counters[0] = triangles reserved, counters[1] = jobs reserved (both may overshoot the capacities), counters[2] =
+// workgroups of the job kernel that are done; all zero between calls (the job kernel's last workgroup re-zeroes them)
+struct HugeQueue {
+    uint32_t *counters;
+    HugeTri *tris;
+    HugeJob *jobs;
+    uint32_t tri_cap, job_cap;  // <= kQueueTriangles / kQueueJobs
+};
+
 struct RasterConst {
     float vp[16];  // proj * view, column-major
     float wf, hf;
@@ -103,7 +132,7 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     const mcull_visible *__restrict__ list, const unsigned long long *__restrict__ total, uint64_t capacity,
     const mcull_meshlet *__restrict__ meshlets, const uint32_t *__restrict__ meshlet_data,
     const mcull_vertex *__restrict__ vertices, const float *__restrict__ transforms, RasterConst rc,
-    uint32_t *__restrict__ depth_bits, const ViewConst *__restrict__ view_dev) {
+    uint32_t *__restrict__ depth_bits, const ViewConst *__restrict__ view_dev, HugeQueue queue) {
     const uint32_t lane = threadIdx.x & 63u;
     // the wave index is made provably wave-uniform, so that the list entry, the meshlet header and
     // the matrix are fetched with scalar loads into SGPRs
@@ -261,6 +290,27 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
                     b.x2 = __shfl(cur.x2, src); b.y2 = __shfl(cur.y2, src); b.z2 = __shfl(cur.z2, src);
                     const float b_area = __shfl(area, src);
                     const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
+                    if (ow * oh > kHugeBox) {
+                        // hand the box to the job kernel: one reservation by lane 0, the records written by the wave
+                        const uint32_t ntx = (ow + kJobTile - 1u) / kJobTile, n_jobs = ntx * ((oh + kJobTile - 1u) / kJobTile);
+                        uint32_t tri_idx = 0, job_base = 0;
+                        if (lane == 0) {
+                            tri_idx = atomicAdd(queue.counters, 1u);
+                            job_base = atomicAdd(queue.counters + 1, n_jobs);
+                        }
+                        tri_idx = __builtin_amdgcn_readfirstlane(tri_idx);
+                        job_base = __builtin_amdgcn_readfirstlane(job_base);
+                        const bool fits = tri_idx < queue.tri_cap && job_base + n_jobs <= queue.job_cap && job_base + n_jobs >= job_base;
+                        if (fits && lane == 0) {
+                            HugeTri rec = {b.x0, b.y0, b.z0, b.x1, b.y1, b.z1, b.x2, b.y2, b.z2, ox | (oy << 16), (ow - 1u) | ((oh - 1u) << 16), 0u};
+                            queue.tris[tri_idx] = rec;
+                        }
+                        // reserved job slots inside the queue are always written: real pieces, or "nothing to do" when
+                        // the reservation does not fit as a whole (the box is then walked here, as a box below the limit is)
+                        for (uint32_t j = lane; j < n_jobs && job_base + j < queue.job_cap && job_base + j >= job_base; j += 64u)
+                            queue.jobs[job_base + j] = HugeJob{fits ? tri_idx : 0xffffffffu, (j % ntx) | ((j / ntx) << 16)};
+                        if (fits) continue;
+                    }
                     const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
                                t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
                     // the wave covers the box in 8x8-pixel tiles, lane = (lane & 7, lane >> 3) inside the tile
@@ -275,10 +325,82 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     }
 }
 
+// The queued pieces of huge boxes, one wave per piece.  A piece whose four corner pixel centres all lie outside the
+// same edge holds no covered pixel - each edge function, as evaluated, is monotonic in x for a fixed y and in y for a
+// fixed x (rounding preserves order), so over a rectangle of pixel centres its minimum is taken at a corner - and
+// is skipped without touching its pixels.
+__global__ __launch_bounds__(kRasterBlock) void depth_raster_jobs_kernel(HugeQueue queue, uint32_t w, uint32_t *__restrict__ depth_bits) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = blockIdx.x * (kRasterBlock / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kRasterBlock / 64);
+    uint32_t n = queue.counters[1];
+    if (n == 0u) return;  // the usual case: no huge box this call (then no triangle was reserved either, nothing to re-zero)
+    if (n > queue.job_cap) n = queue.job_cap;
+    for (uint32_t j = wave0; j < n; j += n_waves) {
+        const HugeJob job = queue.jobs[j];
+        if (job.tri == 0xffffffffu) continue;
+        const HugeTri t = queue.tris[job.tri];
+        Tri b = {t.x0, t.y0, t.z0, t.x1, t.y1, t.z1, t.x2, t.y2, t.z2};
+        const float area = (b.x1 - b.x0) * (b.y2 - b.y0) - (b.x2 - b.x0) * (b.y1 - b.y0);
+        const bool t0 = edge_top_left(b.x1, b.y1, b.x2, b.y2), t1 = edge_top_left(b.x2, b.y2, b.x0, b.y0),
+                   t2 = edge_top_left(b.x0, b.y0, b.x1, b.y1);
+        const uint32_t ox = (t.origin & 0xffffu) + kJobTile * (job.piece & 0xffffu), oy = (t.origin >> 16) + kJobTile * (job.piece >> 16);
+        const uint32_t ex = (t.origin & 0xffffu) + (t.extent & 0xffffu), ey = (t.origin >> 16) + (t.extent >> 16);  // last pixel of the box
+        const uint32_t ow = min(kJobTile, ex - ox + 1u), oh = min(kJobTile, ey - oy + 1u);
+        // corner test (lanes 0-3 take one corner each)
+        {
+            const float cx = (float)(ox + ((lane & 1u) ? ow - 1u : 0u)) + 0.5f, cy = (float)(oy + ((lane & 2u) ? oh - 1u : 0u)) + 0.5f;
+            const float w0 = edge_fn(b.x1, b.y1, b.x2, b.y2, cx, cy), w1 = edge_fn(b.x2, b.y2, b.x0, b.y0, cx, cy),
+                        w2 = edge_fn(b.x0, b.y0, b.x1, b.y1, cx, cy);
+            const bool corner = lane < 4u;
+            const bool out0 = !(w0 < 0.0f || (w0 == 0.0f && t0)), out1 = !(w1 < 0.0f || (w1 == 0.0f && t1)),
+                       out2 = !(w2 < 0.0f || (w2 == 0.0f && t2));
+            const uint64_t four = 0xfull;
+            if ((__ballot(corner && out0) & four) == four || (__ballot(corner && out1) & four) == four ||
+                (__ballot(corner && out2) & four) == four)
+                continue;
+        }
+        for (uint32_t ty = lane >> 3; ty < oh; ty += 8u)
+            for (uint32_t tx = lane & 7u; tx < ow; tx += 8u)
+                raster_pixel(b, area, t0, t1, t2, ox + tx, oy + ty, w, depth_bits);
+    }
+    // every workgroup has read the job count before it gets here; the last one leaves the counters zero for the next call
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(queue.counters + 2, 1u) == gridDim.x - 1u) {
+        queue.counters[0] = 0u;
+        queue.counters[1] = 0u;
+        queue.counters[2] = 0u;
+    }
+}
+
+size_t depth_raster_scratch_bytes() { return 256 + sizeof(HugeTri) * kQueueTriangles + sizeof(HugeJob) * kQueueJobs; }
+
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
                                const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               hipStream_t st, const ViewConst *view_dev) {
+                               void *scratch, hipStream_t st, const ViewConst *view_dev) {
+    // scratch: depth_raster_scratch_bytes() of device memory (counters - zero before the first call -, the triangle
+    // table, the job queue)
+    HugeQueue queue;
+    queue.counters = reinterpret_cast<uint32_t *>(scratch);
+    queue.tris = reinterpret_cast<HugeTri *>(reinterpret_cast<uint8_t *>(scratch) + 256);
+    queue.jobs = reinterpret_cast<HugeJob *>(reinterpret_cast<uint8_t *>(scratch) + 256 + sizeof(HugeTri) * kQueueTriangles);
+    // evaluation switch MCULL_RASTER_QUEUE="<triangles>,<jobs>": a smaller queue, so that tests reach the path taken
+    // when it is full (the image does not depend on it)
+    static const uint2 caps = [] {
+        uint2 c = make_uint2(kQueueTriangles, kQueueJobs);
+        if (const char *e = std::getenv("MCULL_RASTER_QUEUE")) {
+            char *end = nullptr;
+            const unsigned long t = std::strtoul(e, &end, 10);
+            const unsigned long j = (end && *end == ',') ? std::strtoul(end + 1, nullptr, 10) : kQueueJobs;
+            c.x = (uint32_t)(t < kQueueTriangles ? t : kQueueTriangles);
+            c.y = (uint32_t)(j < kQueueJobs ? j : kQueueJobs);
+        }
+        return c;
+    }();
+    queue.tri_cap = caps.x;
+    queue.job_cap = caps.y;
+    hipError_t e;
     RasterConst rc;
     for (int i = 0; i < 16; i++) rc.vp[i] = vp ? vp[i] : 0.0f;
     rc.w = w; rc.h = h;
@@ -298,11 +420,17 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
     }();
     if (view_dev)
         hipLaunchKernelGGL(depth_raster_kernel<true>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
-                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth), view_dev);
+                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth), view_dev, queue);
     else
         hipLaunchKernelGGL(depth_raster_kernel<false>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
                            capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth),
-                           (const ViewConst *)nullptr);
+                           (const ViewConst *)nullptr, queue);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // a fixed grid of an eighth of the main one: an empty queue (the usual case) costs the same 4.5 us of launch
+    // whatever the grid, and a twentieth was slower on a screen-filling quad (0.127 against 0.082 ms at 3840x2160)
+    hipLaunchKernelGGL(depth_raster_jobs_kernel, dim3(grid / 8u ? grid / 8u : 1u), dim3(kRasterBlock), 0, st, queue, w,
+                       reinterpret_cast<uint32_t *>(depth));
     return hipGetLastError();
 }
 

@@ -52,6 +52,7 @@ struct mcull_ctx {
     HizSlot hiz[MCULL_MAX_VIEWS];
     DevBuf depth_staging, hiz_counter;
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
+    DevBuf raster_scratch;  // the rasteriser's queue of huge triangles
     DevBuf view_dev;  // MCULL_MAX_VIEWS + 1 device-resident ViewConst records (the *_device_globals calls; the last one is the rasteriser's)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
@@ -267,7 +268,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev};
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
         for (DevBuf *b : {&o.mask, &o.tile_counts, &o.super_counts, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
@@ -992,6 +993,10 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
         if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
         view_dev = (const mcull::ViewConst *)c->view_dev.p + MCULL_MAX_VIEWS;  // the rasteriser's own record
     }
+    if (!c->raster_scratch.p) {
+        if (int rc = ensure(c, c->raster_scratch, mcull::depth_raster_scratch_bytes())) return rc;
+        HIPCHK(c, hipMemsetAsync(c->raster_scratch.p, 0, 256, c->stream));  // the queue counters; the kernels keep them zero between calls
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (view_dev) {
         hipLaunchKernelGGL(derive_view_kernel, dim3(1), dim3(64), 0, c->stream, g_dev, mcull::ViewConst{},
@@ -1001,7 +1006,7 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     HIPCHK(c, mcull::launch_depth_raster(o.last.list, (const uint64_t *)o.total_ptr, o.last.capacity,
                                          (const mcull_meshlet *)c->aos.p, (const uint32_t *)c->mdata.p,
                                          (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, g ? vp : nullptr,
-                                         width, height, (float *)c->depth.p, c->stream, view_dev));
+                                         width, height, (float *)c->depth.p, c->raster_scratch.p, c->stream, view_dev));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;

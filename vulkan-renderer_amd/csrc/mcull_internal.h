@@ -88,7 +88,8 @@ hipError_t gpu_build_meshlets(const uint32_t *indices, uint32_t n_tri, std::vect
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
                                const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               hipStream_t st, const ViewConst *view_dev = nullptr);
+                               void *scratch, hipStream_t st, const ViewConst *view_dev = nullptr);
+size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs as `scratch`
 
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero)
 constexpr size_t kHizCounterBytes = 2048;
