@@ -353,7 +353,7 @@ def _screen_filling_scene(mc, rs, n_quads):
 
 @pytest.mark.parametrize("queue", [None, "3,40", "1,1", "0,0", "1000,7"])
 def test_huge_triangles_go_through_the_job_queue(mc, O, monkeypatch, queue):
-    """Boxes above 128x128 pixels are cut into pieces for a second kernel.  Same image as the oracle's, with the
+    """Boxes above 512 pixels are cut into 64x64 pieces for a second kernel.  Same image as the oracle's, with the
     default queue and with queues so small that some or all of the triangles are walked in place instead."""
     if queue is not None:
         monkeypatch.setenv("MCULL_RASTER_QUEUE", queue)

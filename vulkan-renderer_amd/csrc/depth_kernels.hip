@@ -32,9 +32,13 @@ constexpr uint32_t kSmallBox = 32;
 // A box above kHugeBox pixels is not walked by the wave that found it: the triangle goes into a table and its
 // box, cut into kJobTile x kJobTile pixel pieces, into a job queue that a second kernel spreads over the whole
 // device (one wave per piece).  Without it a single screen-filling quad keeps ONE wave busy for 35 ms at
-// 3840x2160 (2 ms at 800x600, 284 ms at 8192^2) while the rest of the device idles.  Same expressions on
-// the same screen-space values, merged by the same atomic maximum: the image does not change.
-constexpr uint32_t kHugeBox = 128u * 128u;
+// 3840x2160 (2 ms at 800x600, 284 ms at 8192^2) while the rest of the device idles, and a mesh seen from close by
+// (triangles of hundreds of pixels) leaves most of the device waiting for the few waves that own them.  Same
+// expressions on the same screen-space values, merged by the same atomic maximum: the image does not change.
+// Limit: kitten close-ups at 3840x2160 (1 instance / 8 instances / 1 very close) take 0.31 / 0.27 / 0.21 ms with
+// 512, 0.33 / 0.29 / 0.27 with 1024, 0.84 / 0.31 / 1.50 with 16384, 0.34 / 0.67 / 0.22 with 256 (the queue fills);
+// the reference scene at 800x600 and sub-pixel triangles measure the same with any of them.
+constexpr uint32_t kHugeBox = 512u;
 constexpr uint32_t kJobTile = 64u;
 constexpr uint32_t kQueueTriangles = 1u << 16;   // 3 MB of triangle records
 constexpr uint32_t kQueueJobs = 1u << 20;        // 8 MB of jobs; what does not fit is walked in place as before
@@ -62,7 +66,7 @@ struct RasterConst {
     float vp[16];  // proj * view, column-major
     float wf, hf;
     uint32_t w, h;
-    uint32_t small_box;
+    uint32_t small_box, huge_box;
 };
 
 struct Tri {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
                     b.x2 = __shfl(cur.x2, src); b.y2 = __shfl(cur.y2, src); b.z2 = __shfl(cur.z2, src);
                     const float b_area = __shfl(area, src);
                     const uint32_t ox = __shfl(bx, src), oy = __shfl(by, src), ow = __shfl(bw, src), oh = __shfl(bh, src);
-                    if (ow * oh > kHugeBox) {
+                    if (ow * oh > rc.huge_box) {
                         // hand the box to the job kernel: one reservation by lane 0, the records written by the wave
                         const uint32_t ntx = (ow + kJobTile - 1u) / kJobTile, n_jobs = ntx * ((oh + kJobTile - 1u) / kJobTile);
                         uint32_t tri_idx = 0, job_base = 0;
@@ -406,6 +410,11 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
     rc.w = w; rc.h = h;
     rc.wf = (float)w; rc.hf = (float)h;
     rc.small_box = kSmallBox;
+    static const uint32_t huge_box = [] {  // evaluation switch: the box size from which triangles are queued
+        const char *e = std::getenv("MCULL_RASTER_HUGE");
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kHugeBox;
+    }();
+    rc.huge_box = huge_box;
     // The entry count lives on the device: a fixed grid whose waves stride over the list.  The grid is
     // exactly what the device holds at once (a larger one would run as a full batch followed by a
     // partial one, each wave of either doing the same share of the list).
