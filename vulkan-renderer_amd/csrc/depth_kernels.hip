@@ -36,7 +36,7 @@ constexpr uint32_t kSmallBox = 32;
 // (triangles of hundreds of pixels) leaves most of the device waiting for the few waves that own them.  Same
 // expressions on the same screen-space values, merged by the same atomic maximum: the image does not change.
 // Limit: kitten close-ups at 3840x2160 (1 instance / 8 instances / 1 very close) take 0.31 / 0.27 / 0.21 ms with
-// 512, 0.33 / 0.29 / 0.27 with 1024, 0.84 / 0.31 / 1.50 with 16384, 0.34 / 0.67 / 0.22 with 256 (the queue fills);
+// 512, 0.33 / 0.29 / 0.27 with 1024, 0.84 / 0.31 / 1.50 with 16384, 0.34 / 0.67 / 0.22 with 256 (two reservations and a job per triangle cost more than walking so small a box; a queue four times as large measures the same);
 // the reference scene at 800x600 and sub-pixel triangles measure the same with any of them.
 constexpr uint32_t kHugeBox = 512u;
 constexpr uint32_t kJobTile = 64u;
