@@ -13,7 +13,8 @@
  *   - every function returns MCULL_OK (0) or a negative MCULL_E_* code; nothing
  *     throws across the boundary (the reference's VK_CHECK, utils.hpp:68-79, throws;
  *     the C++ wrapper in mcull.hpp restores that behaviour on top of these codes);
- *   - a context is bound to one device and one stream and is not thread-safe;
+ *   - a context is bound to one device and one stream and is not thread-safe; different
+ *     contexts share nothing and may be driven from different threads at the same time;
  *   - calls are stream-ordered and asynchronous unless the name says download /
  *     synchronize;
  *   - matrices are column-major float[16] exactly as glm::mat4 stores them:
