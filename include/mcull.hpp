@@ -290,15 +290,36 @@ public:
     void loadScene(const std::string &path) {
         for (uint32_t r = 0; r < shardCount(); r++) MCULL_CHECK(shard(r), mcull_scene_upload(shard(r), path.c_str()));
     }
-    // binding 4, split: shard r receives transforms [firstInstance(r), firstInstance(r + 1))
-    void updateTransforms(const std::vector<Transform> &transforms) {
+    // binding 4, split into contiguous ranges: evenly by instance count, or - with the number of meshlets each
+    // instance draws - so that every shard tests about the same number of meshlet-instances (scenes mixing meshes)
+    void updateTransforms(const std::vector<Transform> &transforms, const std::vector<uint32_t> *meshletsPerInstance = nullptr) {
         const uint32_t n = shardCount();
-        for (uint32_t r = 0; r < n; r++) {
-            const uint64_t b = firstInstance(transforms.size(), n, r), e = firstInstance(transforms.size(), n, r + 1);
-            MCULL_CHECK(shard(r), mcull_upload_transforms(shard(r), transforms.data() + b, e - b, MCULL_MEM_HOST));
+        cuts_.assign(n + 1, 0);
+        if (meshletsPerInstance && meshletsPerInstance->size() == transforms.size()) {
+            uint64_t total = 0;
+            for (uint32_t c : *meshletsPerInstance) total += c;
+            uint64_t run = 0, i = 0;
+            for (uint32_t r = 1; r < n; r++) {
+                while (i < transforms.size() && run < total * r / n) run += (*meshletsPerInstance)[i++];
+                cuts_[r] = i;
+            }
+        } else {
+            for (uint32_t r = 1; r < n; r++) cuts_[r] = firstInstance(transforms.size(), n, r);
         }
+        cuts_[n] = transforms.size();
+        for (uint32_t r = 0; r < n; r++)
+            MCULL_CHECK(shard(r), mcull_upload_transforms(shard(r), transforms.data() + cuts_[r], cuts_[r + 1] - cuts_[r], MCULL_MEM_HOST));
         instances_ = transforms.size();
     }
+    // per-instance meshlet ranges of the whole scene, cut like the transforms (call after updateTransforms)
+    void setInstanceRanges(const std::vector<uint32_t> &offset, const std::vector<uint32_t> &count) {
+        if (offset.size() != instances_ || count.size() != instances_ || cuts_.size() != shardCount() + 1)
+            throw std::runtime_error("mcull error: ranges must cover the instances given to updateTransforms");
+        for (uint32_t r = 0; r < shardCount(); r++)
+            MCULL_CHECK(shard(r), mcull_set_instance_ranges(shard(r), offset.data() + cuts_[r], count.data() + cuts_[r], cuts_[r + 1] - cuts_[r]));
+    }
+    // first instance of every shard, then the instance count
+    const std::vector<uint64_t> &cuts() const { return cuts_; }
     void buildHiZPyramid(const float *hostDepth, uint32_t width, uint32_t height, uint32_t view = 0) {
         for (uint32_t r = 0; r < shardCount(); r++)
             MCULL_CHECK(shard(r), mcull_hiz_build(shard(r), view, hostDepth, width, height, MCULL_MEM_HOST));
@@ -338,6 +359,7 @@ private:
     mcull_group *grp_ = nullptr;
     uint64_t instances_ = 0;
     uint32_t stride_ = 8;
+    std::vector<uint64_t> cuts_;
 };
 
 }  // namespace mcull
