@@ -407,7 +407,7 @@ def run_cull(env, workload):
             algo = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in vis_views)
         else:
             algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
-        kernels = "cull_mask_kernel + compact_kernel + emit_commands_kernel (one step)"
+        kernels = "cull_mask_kernel + super_sum_kernel + compact_kernel + emit_commands_kernel (one step)"
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / n_pairs, 4),
                      "parallelism": ("instances sharded x%d, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % world)
                      if multi else "single GPU"}
@@ -465,7 +465,7 @@ def pmc_traffic(args, workload, n_inst, per):
     """Traffic of one step of the profiled default workload, or None when the workload differs."""
     if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False):
         return None, None
-    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "compact_kernel", "emit_commands_kernel"))
+    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "super_sum_kernel", "compact_kernel", "emit_commands_kernel"))
 
 
 def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):
