@@ -255,6 +255,23 @@ int mcull_hiz_download_level(mcull_ctx *ctx, uint32_t view, uint32_t level, floa
 int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
                mcull_cull_result *result);
 
+/* mcull_cull for callers that cannot allocate device memory: code under HIP graph capture, tight frame
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same kernels and results as
+ * mcull_cull with ordered compaction, but the call performs no hipMalloc / hipFree: `params` must bring the
+ * caller-owned device outputs list (+ list_capacity), commands and total, and the intermediate buffers
+ * (visibility ballots, tile counters, per-instance list offsets) live in a static device array of
+ * MCULL_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * Limits: at most MCULL_STATIC_MAX_GROUPS 64-meshlet groups (134 M meshlet-instances) and
+ * MCULL_STATIC_MAX_INSTANCES instances, else MCULL_E_CAPACITY.  All contexts of one GPU share that array:
+ * calls that overlap on one GPU (two streams, two threads) race; result->mask / first_task point into it
+ * and stay valid only until the next mcull_cull_static on that GPU.  The context's stored result (what the
+ * download / rebase / payload / rasterise calls refer to) is left untouched. */
+#define MCULL_STATIC_MAX_GROUPS 2097152ull
+#define MCULL_STATIC_MAX_INSTANCES 1048576ull
+#define MCULL_STATIC_SCRATCH_BYTES 21005056ull
+int mcull_cull_static(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
+                      mcull_cull_result *result);
+
 /* mcull_cull for up to MCULL_MAX_VIEWS views of the same scene in one pass over the meshlet bounds
  * (the cascade / multi-camera case: the reference records one cull per render pass, Engine.cpp:2381-2551,
  * and has no multi-view form).  globals[i] / params[i] (params may be NULL: all tests, ordered) /

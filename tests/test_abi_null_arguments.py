@@ -24,7 +24,7 @@ calls = {
  "mcull_compute_bounds": (None,), "mcull_download_meshlets": (None, P, 1), "mcull_upload_transforms": (None, P, 1, 0),
  "mcull_set_instance_ranges": (None, P, P, 1), "mcull_hiz_build": (None, 0, P, 4, 4, 0),
  "mcull_hiz_pyramid": (None, 0, None, None), "mcull_hiz_download_level": (None, 0, 0, P),
- "mcull_cull": (None, P, None, None), "mcull_cull_views": (None, 1, P, None, None), "mcull_select_result": (None, 0),
+ "mcull_cull": (None, P, None, None), "mcull_cull_static": (None, P, None, None), "mcull_cull_views": (None, 1, P, None, None), "mcull_select_result": (None, 0),
  "mcull_cull_device_globals": (None, P, 1, None, None), "mcull_cull_views_device_globals": (None, 1, P, 1, None, None),
  "mcull_rebase_commands": (None, P, 0), "mcull_task_payload_count": (None,), "mcull_emit_task_payloads": (None, P),
  "mcull_download_count": (None, None), "mcull_download_list": (None, P, 1, None), "mcull_download_commands": (None, P, 8),

@@ -48,6 +48,7 @@ COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
 CMD_NV_MESHLETS, CMD_EXT_GROUPS = 0, 1
 CMD_EXT = np.dtype([("groupCountX", "<u4"), ("groupCountY", "<u4"), ("groupCountZ", "<u4")])
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
+STATIC_MAX_GROUPS, STATIC_MAX_INSTANCES, STATIC_SCRATCH_BYTES = 2097152, 1048576, 21005056
 
 # every symbol include/mcull.h declares
 ABI_SYMBOLS = [
@@ -63,7 +64,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
-    "mcull_cull_views_device_globals",
+    "mcull_cull_views_device_globals", "mcull_cull_static",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
 ]
@@ -112,6 +113,7 @@ _sig("mcull_hiz_build", _I, [_P, _U32, _P, _U32, _U32, _I])
 _sig("mcull_hiz_pyramid", _I, [_P, _U32, C.POINTER(_P), C.POINTER(_U64)])
 _sig("mcull_hiz_download_level", _I, [_P, _U32, _U32, _P])
 _sig("mcull_cull", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
+_sig("mcull_cull_static", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
 _sig("mcull_rebase_commands", _I, [_P, _P, _U32])
 _sig("mcull_task_payload_count", _U64, [_P])
 _sig("mcull_emit_task_payloads", _I, [_P, _P])
@@ -517,6 +519,18 @@ class Context:
         r = CullResult()
         self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
+        return r
+
+    def cull_static(self, globals_, list_ptr, list_capacity, commands_ptr, total_ptr, tests=TEST_ALL, hiz_view=0,
+                    cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0):
+        """cull() without any device allocation (mcull_cull_static): ordered compaction into caller-owned
+        list / commands / total; the intermediate buffers are the GPU's static scratch array.  The context's
+        stored result (download_*, rebase, payloads) is not touched."""
+        g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
+        p = CullParams(tests, COMPACT_ORDERED, hiz_view, cmd_form, cmd_stride, cmd_offset, 0, 0,
+                       list_ptr, list_capacity, commands_ptr, total_ptr)
+        r = CullResult()
+        self._chk(lib.mcull_cull_static(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
         return r
 
     def cull_device_globals(self, device_globals_ptr, meshlet_count, tests=TEST_ALL, hiz_view=0, cmd_form=CMD_NV_MESHLETS,

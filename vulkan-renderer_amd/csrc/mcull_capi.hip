@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,8 +33,53 @@ struct HizSlot {
 
 }  // namespace
 
+// Scratch of mcull_cull_static, the entry point that allocates nothing: the visibility ballots, the tile
+// counters and their second level, and the per-instance list offsets of one ordered cull of at most
+// MCULL_STATIC_MAX_GROUPS groups and MCULL_STATIC_MAX_INSTANCES instances.  Every GPU the library runs on holds
+// its own copy of this array until the process ends.  Host code never uses the array's name as an address:
+// mcull_create asks the runtime for the copy's device address once per device (scratch_address) and every
+// later use goes through that pointer.
+namespace {
+constexpr size_t kStaticMaskBytes = (size_t)MCULL_STATIC_MAX_GROUPS * 8;
+constexpr size_t kStaticTileBytes = ((size_t)MCULL_STATIC_MAX_GROUPS / 256 + 1) * 4;      // one counter per 256 groups
+constexpr size_t kStaticSuperBytes = ((size_t)MCULL_STATIC_MAX_GROUPS / 65536 + 1) * 4;   // one sum per 256 counters
+constexpr size_t kStaticFirstBytes = ((size_t)MCULL_STATIC_MAX_INSTANCES + 1) * 4;
+constexpr size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+constexpr size_t kStaticMaskOff = 0;
+constexpr size_t kStaticTileOff = kStaticMaskOff + align256(kStaticMaskBytes);
+constexpr size_t kStaticSuperOff = kStaticTileOff + align256(kStaticTileBytes);
+constexpr size_t kStaticFirstOff = kStaticSuperOff + align256(kStaticSuperBytes);
+constexpr size_t kStaticBytes = kStaticFirstOff + align256(kStaticFirstBytes);
+static_assert(kStaticBytes == MCULL_STATIC_SCRATCH_BYTES, "mcull.h states the size of the static scratch");
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_lock;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each device, once resolved
+
+// Device address of this device's copy of `scratch`; the device must be current.
+hipError_t scratch_address(int device, unsigned char **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct mcull_ctx {
     int device = 0;
+    unsigned char *static_scratch = nullptr;  // this device's copy of `scratch` (never the array's name)
     int cu_count = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -252,6 +298,13 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
         return MCULL_E_HIP;
     }
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // the device is current: resolve the address of its copy of the static scratch once
+    if (scratch_address(device_ordinal, &c->static_scratch) != hipSuccess) {
+        (void)hipEventDestroy(c->ev0);
+        (void)hipEventDestroy(c->ev1);
+        delete c;
+        return MCULL_E_HIP;
+    }
     // The pyramid scheme is chosen by image size (launch_hiz); these switches force one of the schemes
     // for evaluation and tests (results are identical)
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
@@ -576,10 +629,10 @@ struct CullPlan {
     uint32_t n_tiles;
 };
 
+// The half of the plan that allocates nothing: validated parameters, scene and view constants, sizes.
 // g == nullptr: the Globals are in device memory; the view-dependent constants stay zero here (a kernel
 // derives them) and meshlet_count stands in for globals.meshletCount.
-int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, const mcull_cull_params *params, mcull_ctx::ViewOut &o,
-              CullPlan *plan) {
+int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, const mcull_cull_params *params, CullPlan *plan) {
     if (!c->have_bounds) return fail(c, MCULL_E_STATE, "no meshlet bounds uploaded");
     mcull_cull_params &p = plan->p;
     std::memset(&p, 0, sizeof p);
@@ -641,9 +694,22 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
         v.level_table = (const uint32_t *)hs.table.p;
         v.pyramid = (const float *)hs.pyramid.p;
     }
-
-    int rc;
     plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
+    plan->n_tiles = mcull::tile_count_for(s.n_groups);
+    plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
+    plan->two_level = mcull::needs_super_counts(s.n_groups);
+    // bounds that cannot stay cache-resident between culls are read with the streaming hint
+    plan->streaming = c->force_streaming || c->n_meshlets * 32ull > (64ull << 20);
+    return MCULL_OK;
+}
+
+// The other half: the output and scratch buffers of one view slot (allocated or grown here).
+int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, const mcull_cull_params *params, mcull_ctx::ViewOut &o,
+              CullPlan *plan) {
+    if (int rc0 = plan_inputs(c, g, meshlet_count, params, plan)) return rc0;
+    mcull_cull_params &p = plan->p;
+    mcull::SceneDev &s = plan->s;
+    int rc;
     if (plan->want_mask && (rc = ensure(c, o.mask, s.n_groups * 8))) return rc;
     if ((rc = ensure(c, o.total, 256))) return rc;
     plan->total = p.total ? p.total : (uint64_t *)o.total.p;
@@ -666,11 +732,6 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
         o.commands_layout = layout_key;
         plan->commands = o.commands.p;
     }
-    plan->n_tiles = mcull::tile_count_for(s.n_groups);
-    plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
-    plan->two_level = mcull::needs_super_counts(s.n_groups);
-    // bounds that cannot stay cache-resident between culls are read with the streaming hint
-    plan->streaming = c->force_streaming || c->n_meshlets * 32ull > (64ull << 20);
     if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
@@ -783,6 +844,61 @@ int mcull_cull_device_globals(mcull_ctx *c, const mcull_globals *device_globals,
                               const mcull_cull_params *params, mcull_cull_result *result) {
     if (c && !device_globals) return fail(c, MCULL_E_INVALID, "device_globals is null");
     return cull_impl(c, nullptr, device_globals, meshlet_count, params, result);
+}
+
+// mcull_cull without any allocation: outputs are the caller's, scratch is this device's static array.
+int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_params *params, mcull_cull_result *result) {
+    if (!c) return MCULL_E_INVALID;
+    if (!g) return fail(c, MCULL_E_INVALID, "globals is null");
+    if (!params || !params->list || !params->commands || !params->total)
+        return fail(c, MCULL_E_INVALID, "mcull_cull_static needs caller-owned list, commands and total");
+    if (params->compaction != MCULL_COMPACT_ORDERED)
+        return fail(c, MCULL_E_INVALID, "mcull_cull_static supports ordered compaction only");
+    HIPCHK(c, hipSetDevice(c->device));
+    CullPlan pl;
+    if (int rc = plan_inputs(c, g, 0, params, &pl)) return rc;
+    if (pl.s.n_groups > MCULL_STATIC_MAX_GROUPS)
+        return fail(c, MCULL_E_CAPACITY, "mcull_cull_static: %llu meshlet groups, the static scratch holds %llu",
+                    (unsigned long long)pl.s.n_groups, (unsigned long long)MCULL_STATIC_MAX_GROUPS);
+    if (c->n_instances > MCULL_STATIC_MAX_INSTANCES)
+        return fail(c, MCULL_E_CAPACITY, "mcull_cull_static: %llu instances, the static scratch holds %llu",
+                    (unsigned long long)c->n_instances, (unsigned long long)MCULL_STATIC_MAX_INSTANCES);
+    unsigned char *ptr = c->static_scratch;  // resolved by mcull_create with this device current
+    if (!ptr) return fail(c, MCULL_E_STATE, "the static scratch of device %d was never resolved", c->device);
+    uint64_t *mask = reinterpret_cast<uint64_t *>(ptr + kStaticMaskOff);
+    uint32_t *tile_counts = reinterpret_cast<uint32_t *>(ptr + kStaticTileOff);
+    uint32_t *super_counts = reinterpret_cast<uint32_t *>(ptr + kStaticSuperOff);
+    uint32_t *inst_first = reinterpret_cast<uint32_t *>(ptr + kStaticFirstOff);
+    pl.total = params->total;
+    pl.list = params->list;
+    pl.capacity = params->list_capacity;
+    pl.commands = params->commands;
+    if (pl.s.n_groups == 0) {
+        // no pair at all: zero commands from zero per-instance counts (kept in the inst_first region)
+        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(inst_first, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, inst_first, (const uint64_t *)pl.total, nullptr,
+                                              0, pl.lay, pl.commands, nullptr, c->stream));
+    } else {
+        // the array keeps the previous call's contents (any context of this GPU may have made it): the
+        // counters the mask pass adds into start at zero
+        HIPCHK(c, hipMemsetAsync(tile_counts, 0, (size_t)pl.n_tiles * 4, c->stream));
+        HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, mask, tile_counts, pl.streaming, c->stream, nullptr));
+        HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? super_counts : nullptr, pl.list, pl.capacity,
+                                        inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
+        HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, inst_first, nullptr, (const uint64_t *)pl.total, nullptr, 0,
+                                              pl.lay, pl.commands, tile_counts, c->stream));
+    }
+    if (result) {
+        result->list = pl.list;
+        result->commands = pl.commands;
+        result->total = (const uint64_t *)pl.total;
+        result->mask = pl.s.n_groups > 0 ? mask : nullptr;
+        result->n_groups = pl.s.n_groups;
+        result->n_pairs = pl.n_pairs;
+        result->first_task = pl.s.n_groups > 0 ? inst_first : nullptr;
+    }
+    return MCULL_OK;
 }
 
 namespace {
