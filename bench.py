@@ -44,25 +44,52 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def make_scene(device, n_inst, per, seed):
-    """Synthetic scene on the device: unique meshlets per instance, random rigid transforms."""
-    gen = torch.Generator(device=device).manual_seed(seed)
+SCENE_CHUNK = 1250  # instances per generator chunk (781 250 = 625 chunks)
+
+
+def _chunk_gen(device, seed, chunk):
+    """The generator of one chunk of a synthetic scene: seeded by (scene seed, chunk index) alone, so any
+    rank can generate any contiguous range of instances locally and the shards of a scene concatenate to
+    exactly the scene a single rank generates."""
+    return torch.Generator(device=device).manual_seed(seed * 1_000_003 + chunk)
+
+
+def make_transforms_range(device, first, n_inst, extent, seed):
+    """Random rigid transforms of instances [first, first + n_inst) of the scene `seed`."""
+    out = torch.empty((n_inst, 16), device=device, dtype=torch.float32)
+    c0, c1 = first // SCENE_CHUNK, (first + n_inst + SCENE_CHUNK - 1) // SCENE_CHUNK
+    for ch in range(c0, c1):
+        gen = _chunk_gen(device, seed ^ 0x5bd1e995, ch)
+        m = make_transforms(device, SCENE_CHUNK, extent, gen)
+        a, b = max(first, ch * SCENE_CHUNK), min(first + n_inst, (ch + 1) * SCENE_CHUNK)
+        out[a - first:b - first] = m[a - ch * SCENE_CHUNK:b - ch * SCENE_CHUNK]
+    return out
+
+
+def make_scene_range(device, first, n_inst, per, seed):
+    """Instances [first, first + n_inst) of the synthetic scene `seed`: `per` unique meshlets per instance
+    (unit-cube centres, radius U(0.01, 0.05), axis uniform on the sphere, coneW U(0,1) with 10 % set to 1),
+    random rigid transforms over +-50.  Returns (cone_axis_w, centre_radius, transforms) on the device."""
     n = n_inst * per
     cone = torch.empty((n, 4), device=device, dtype=torch.float32)
-    chunk = 1 << 24
-    for a in range(0, n, chunk):
-        b = min(n, a + chunk)
-        v = torch.randn((b - a, 3), device=device, generator=gen)
-        cone[a:b, :3] = v / v.norm(dim=1, keepdim=True)
-        cw = torch.rand(b - a, device=device, generator=gen)
-        cw[torch.rand(b - a, device=device, generator=gen) < 0.1] = 1.0  # never cone-culled
-        cone[a:b, 3] = cw
     sphere = torch.empty((n, 4), device=device, dtype=torch.float32)
-    for a in range(0, n, chunk):
-        b = min(n, a + chunk)
-        sphere[a:b, :3] = torch.rand((b - a, 3), device=device, generator=gen)
-        sphere[a:b, 3] = 0.01 + 0.04 * torch.rand(b - a, device=device, generator=gen)
-    return cone, sphere, make_transforms(device, n_inst, 50.0, gen)
+    c0, c1 = first // SCENE_CHUNK, (first + n_inst + SCENE_CHUNK - 1) // SCENE_CHUNK
+    rows = SCENE_CHUNK * per
+    for ch in range(c0, c1):
+        gen = _chunk_gen(device, seed, ch)
+        v = torch.randn((rows, 3), device=device, generator=gen)
+        cw = torch.rand(rows, device=device, generator=gen)
+        cw[torch.rand(rows, device=device, generator=gen) < 0.1] = 1.0  # never cone-culled
+        ctr = torch.rand((rows, 3), device=device, generator=gen)
+        rad = 0.01 + 0.04 * torch.rand(rows, device=device, generator=gen)
+        a, b = max(first, ch * SCENE_CHUNK), min(first + n_inst, (ch + 1) * SCENE_CHUNK)
+        src = slice((a - ch * SCENE_CHUNK) * per, (b - ch * SCENE_CHUNK) * per)
+        dst = slice((a - first) * per, (b - first) * per)
+        cone[dst, :3] = (v / v.norm(dim=1, keepdim=True))[src]
+        cone[dst, 3] = cw[src]
+        sphere[dst, :3] = ctr[src]
+        sphere[dst, 3] = rad[src]
+    return cone, sphere, make_transforms_range(device, first, n_inst, 50.0, seed)
 
 
 def make_transforms(device, n_inst, extent, gen):
@@ -78,6 +105,81 @@ def make_transforms(device, n_inst, extent, gen):
     return m.reshape(n_inst, 16).contiguous()
 
 
+def shard_range(n_total, world, rank):
+    """Contiguous instance range [first, first + n) of `rank` when n_total instances are split over `world` ranks."""
+    a, b = (n_total * rank) // world, (n_total * (rank + 1)) // world
+    return a, b - a
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one rank each, with the
+    rendezvous variables torch.distributed.run would set.  This process never touches the GPU (it only
+    starts the children, relays rank 0's stdout - the one JSON line - and returns the first non-zero exit
+    code); the other ranks' stdout goes to stderr."""
+    import subprocess
+    import threading
+
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():
+        for raw in procs[0].stdout:
+            sys.stdout.write(raw.decode(errors="replace"))
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    code = 0
+    live = set(range(n))
+    while live and code == 0:
+        time.sleep(0.1)
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    code = rc
+                    print("bench.py: rank %d exited with status %d" % (r, rc), file=sys.stderr)
+    if code != 0:  # stop exactly the children started here
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    th.join(timeout=10)
+    return code if code >= 0 else 128 - code
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (banners of the collective libraries)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Env:
     """Process-wide state shared by the workloads: ranks, the library, the timing primitives."""
 
@@ -86,7 +188,7 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.world != args.gpus:
+        if self.world != args.gpus:  # main() starts the ranks itself when no launcher did
             raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
         if args.rehearse_shared_gpu:
             # control-flow rehearsal of the multi-rank step on a one-GPU box: every rank uses GPU 0 and the
@@ -104,20 +206,13 @@ class Env:
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
             # RCCL prints a version banner on stdout when its communicator comes up; stdout carries the
             # one JSON line only, so the banner is sent to stderr (communicator creation forced here).
-            sys.stdout.flush()
-            saved_stdout = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with stdout_to_stderr():
                 if args.rehearse_shared_gpu:
                     dist.init_process_group("gloo")
                 else:
                     dist.init_process_group("nccl", device_id=self.device)
                 dist.barrier()
                 torch.cuda.synchronize()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved_stdout, 1)
-                os.close(saved_stdout)
             self.dist = dist
         self.mc = importlib.import_module("vulkan-renderer_amd")  # raises if libmcull.so is missing
         self.host = importlib.import_module("vulkan-renderer_amd.host")
@@ -137,7 +232,7 @@ class Env:
             self.dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(self, step, steps=None, warmup=None):
+    def timed(self, step, steps=None, warmup=None):  # noqa: C901
         """W untimed steps, then K steps between barrier+synchronize fences.  Returns (wall seconds,
         max over ranks; device milliseconds between HIP events on the kernels' stream)."""
         steps = self.args.steps if steps is None else steps
@@ -253,17 +348,24 @@ def time_cpu(fn, budget_s, max_reps=400):
 # ------------------------------------------------------------------------------------------------
 # cull workloads (config 4 = default, config 3, config 5)
 
-def run_cull(env, workload):
+def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False):
+    """One measured leg of a cull workload.  scaling "weak": every rank culls a whole scene of its own
+    (seed 42 + rank); "strong": ONE scene (seed 42) whose instances are split into `world` contiguous
+    shards, rank r generating and culling instances [r*I/N, (r+1)*I/N) - BASELINE config 4 as worded.
+    Returns a dict of measurements (same on every rank where it matters) plus the scene tensors."""
     args, mc, ctx, device = env.args, env.mc, env.ctx, env.device
     rank, world, multi, dist = env.rank, env.world, env.multi, env.dist
+    steps = args.steps if steps is None else steps
     n_views = 1
+    strong = scaling == "strong"
     if workload == "config3":
-        n_inst, per = (args.instances or 1_000_000), (args.meshlets_per_instance or 13916)
-        gen = torch.Generator(device=device).manual_seed(77 + rank)
+        n_scene, per = (args.instances or 1_000_000), (args.meshlets_per_instance or 13916)
+        first, n_inst = shard_range(n_scene, world, rank) if strong else (0, n_scene)
         c_np, s_np = env.host.synthetic_bounds(per, seed=5)  # one shared mesh
         cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
-        xf = make_transforms(device, n_inst, 70.0, gen)
+        xf = make_transforms_range(device, first, n_inst, 70.0, 77 if strong else 77 + rank)
         torch.cuda.synchronize()
+        ctx.set_instance_ranges(None, None)
         ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=per, mem=mc.MEM_DEVICE, adopt=True)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         off = cnt = None
@@ -271,8 +373,9 @@ def run_cull(env, workload):
         use_hiz, hiz_size = True, (3840, 2160)
         unique = per
     else:
-        n_inst, per = (args.instances or 781250), (args.meshlets_per_instance or 128)
-        cone, sphere, xf = make_scene(device, n_inst, per, seed=42 + rank)
+        n_scene, per = (args.instances or 781250), (args.meshlets_per_instance or 128)
+        first, n_inst = shard_range(n_scene, world, rank) if strong else (0, n_scene)
+        cone, sphere, xf = make_scene_range(device, first, n_inst, per, seed=42 if strong else 42 + rank)
         torch.cuda.synchronize()
         off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
         cnt = np.full(n_inst, per, dtype="<u4")
@@ -280,12 +383,17 @@ def run_cull(env, workload):
                               adopt=not args.copy_bounds)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         ctx.set_instance_ranges(off, cnt)
-        g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
+        g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=not args.unflipped)
         use_hiz, hiz_size = args.hiz, (3840, 2160)
         unique = n_inst * per
         if workload == "config5":
             n_views, use_hiz, hiz_size = 8, True, (8192, 8192)
-    n_pairs = n_inst * per
+    n_pairs = n_inst * per                      # this rank's meshlet-instances
+    job_pairs = n_scene * per * (1 if strong else world)  # the whole job's
+    # every rank's command buffer has the rows of the largest shard, so that the all-gather is regular
+    n_rows = shard_range(n_scene, world, 0)[1] if strong else n_inst
+    if strong:
+        n_rows = max(shard_range(n_scene, world, r)[1] for r in range(world))
     tests = mc.TEST_FRUSTUM | mc.TEST_CONE
     views = [g]
     depth = None
@@ -310,13 +418,13 @@ def run_cull(env, workload):
 
     # caller-owned outputs (torch owns what the collectives touch); commands and counts are double
     # buffered so that the gather of step k overlaps the cull of step k+1
-    cap = n_pairs if workload != "config3" else (1 << 30)
-    lst = torch.empty((cap, 2), device=device, dtype=torch.int32)
+    cap = n_pairs if workload != "config3" else min(n_pairs, 1 << 30)
+    lst = torch.empty((max(cap, 1), 2), device=device, dtype=torch.int32)
     # one extra row per command buffer: the visible count (uint64) is written there, so that one
     # all-gather per step carries both the commands and the counts
-    cmds_packed = [torch.zeros((n_inst + 1, 2), device=device, dtype=torch.int32) for _ in range(2)]
+    cmds_packed = [torch.zeros((n_rows + 1, 2), device=device, dtype=torch.int32) for _ in range(2)]
     cmds = [x[:n_inst] for x in cmds_packed]
-    total = [x[n_inst:].view(torch.int64) for x in cmds_packed]
+    total = [x[n_rows:].view(torch.int64) for x in cmds_packed]
     # multi-view: the last view writes the buffers the collectives read; the others stay context-owned
     view_params = [[dict(tests=tests, hiz_view=v) for v in range(n_views)] for _ in range(2)]
     for bb in range(2):
@@ -372,51 +480,80 @@ def run_cull(env, workload):
         if record:
             kernel_ms.append(ms)
 
-    elapsed, dev_ms = env.timed(step)
-    region_ms_per_step = dev_ms / args.steps
+    elapsed, dev_ms = env.timed(step, steps=steps, warmup=warmup)
+    region_ms_per_step = dev_ms / steps
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
-    for k in range(min(args.steps, 10)):
+    for k in range(min(steps, 10)):
         step(k, record=True)
     ctx.enable_timing(False)
     env.fence()
     visible = int(total[0].item())
+    assert visible <= cap, "the visible list (%d entries) does not fit its buffer (%d): the timed steps wrote a truncated list" % (visible, cap)
     with_lists = None
+    job_visible = visible
     if multi:  # the gathered description must be consistent on every rank
         totals_all, cmds_all = gathered[0]
-        assert totals_all.numel() == world and tuple(cmds_all.shape) == (world, n_inst, 2)
+        assert totals_all.numel() == world and tuple(cmds_all.shape) == (world, n_rows, 2)
         mine = cmds_all[rank].to(torch.int64)
-        assert int(mine[:, 0].sum()) == int(totals_all[rank]) and int(mine[0, 1]) == int(totals_all[:rank].sum())
-        if args.gather_lists:
+        assert int(mine[:, 0].sum()) == int(totals_all[rank]) and (int(mine[0, 1]) & 0xffffffff) == (int(totals_all[:rank].sum()) & 0xffffffff)
+        job_visible = int(totals_all.sum())
+        if gather_lists:
             # the same step including the optional all-gather of the visible lists themselves
             # (padded to the largest shard; link-bound over xGMI), timed separately
-            el2, _ = env.timed(lambda k: step(k, gather_lists=True), steps=min(args.steps, 5), warmup=1)
-            n2 = min(args.steps, 5)
-            with_lists = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(n_pairs * n_views * world / (el2 / n2) / 1e9, 3),
+            n2 = min(steps, 5)
+            el2, _ = env.timed(lambda k: step(k, gather_lists=True), steps=n2, warmup=1)
+            with_lists = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(job_pairs * n_views / (el2 / n2) / 1e9, 3),
                           "list_bytes_per_rank": int(totals_all.max()) * 8 * world}
-    value = n_pairs * n_views * world / (elapsed / args.steps) / 1e9
+    hiz_pairs = 0
+    if use_hiz and workload == "config4":
+        # pairs that reach the occlusion test (one 4-byte texel each in the algorithmic bytes): the survivors
+        # of the two arithmetic tests, counted by one untimed cull without the occlusion test
+        ctx.cull(views[0], tests=mc.TEST_FRUSTUM | mc.TEST_CONE, list_ptr=lst.data_ptr(), list_capacity=cap,
+                 commands_ptr=cmds[1].data_ptr(), total_ptr=total[1].data_ptr())
+        env.fence()
+        hiz_pairs = int(total[1].item())
+    vis_views = None
+    if workload == "config5" and not args.separate_views:
+        vis_views = []
+        for v in range(n_views):
+            ctx.select_result(v)
+            vis_views.append(ctx.download_count())
+    return dict(scaling=scaling, elapsed=elapsed, steps=steps, region_ms_per_step=region_ms_per_step,
+                kernel_ms=float(np.mean(kernel_ms)), visible=visible, job_visible=job_visible, with_lists=with_lists,
+                n_inst=n_inst, n_scene=n_scene, per=per, n_pairs=n_pairs, job_pairs=job_pairs, n_views=n_views, unique=unique,
+                tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
+                value=job_pairs * n_views / (elapsed / steps) / 1e9,
+                scene=(cone, sphere, xf, off, cnt))
 
+
+def run_cull(env, workload):
+    args, mc, device = env.args, env.mc, env.device
+    rank, world, multi = env.rank, env.world, env.multi
+    r = cull_leg(env, workload, args.scaling, gather_lists=args.gather_lists)
+    n_inst, per, n_pairs, n_views, unique, visible = r["n_inst"], r["per"], r["n_pairs"], r["n_views"], r["unique"], r["visible"]
+    out = None
     if rank == 0:
-        k_ms = region_ms_per_step if world == 1 else float(np.mean(kernel_ms))
+        k_ms = r["region_ms_per_step"] if world == 1 else r["kernel_ms"]
         if workload == "config5" and not args.separate_views:
             # bounds and transforms are read once for all views; each view writes its own list + commands
-            vis_views = []
-            for v in range(n_views):
-                ctx.select_result(v)
-                vis_views.append(ctx.download_count())
-            algo = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in vis_views)
+            algo = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in r["vis_views"])
         else:
             algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
-        kernels = "cull_mask_kernel + super_sum_kernel + compact_kernel + emit_commands_kernel (one step)"
-        extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / n_pairs, 4),
-                     "parallelism": ("instances sharded x%d, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % world)
+        algo += 4.0 * r["hiz_pairs"]  # config 4 with the occlusion test on: one texel per pair that reaches it
+        kernels = "cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel (one step)"
+        shard_note = ("one %d-instance scene split into %d contiguous shards" % (r["n_scene"], world)) if r["scaling"] == "strong" \
+            else ("one whole scene per GPU")
+        extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / max(n_pairs, 1), 4),
+                     **({"pairs_reaching_hiz": r["hiz_pairs"]} if r["hiz_pairs"] else {}),
+                     "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % shard_note)
                      if multi else "single GPU"}
         if workload == "config5":
-            w, h = hiz_size
+            w, h = r["hiz_size"]
             algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
-            kernels = ("8 x hiz_tile_kernel + cull_mask_views_kernel + 8 x (compact_kernel + emit_commands_kernel)"
+            kernels = ("8 x (hiz_rows_kernel + hiz_tile_kernel) + cull_mask_views_kernel + 8 x (scan_tiles_kernel + compact_kernel + emit_commands_kernel)"
                        if not args.separate_views else
-                       "8 x (hiz_tile_kernel + cull_mask_kernel + compact_kernel + emit_commands_kernel)")
+                       "8 x (hiz_rows_kernel + hiz_tile_kernel + cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel)")
             name = ("config 5: %d instances x %d unique meshlets against 8 views, one 8192^2 Hi-Z pyramid per view rebuilt "
                     "every step, frustum+cone+hiz, ordered compaction, %s (visible fraction is the last view's)"
                     % (n_inst, per, "one pass over the bounds for all views" if not args.separate_views else "one cull per view"))
@@ -426,21 +563,37 @@ def run_cull(env, workload):
                     "counts little more than the visible list and excludes the Hi-Z texel reads" % (n_inst, per, n_pairs))
         else:
             name = ("config 4: synthetic scene, %d instances x %d unique meshlets = %d meshlet-instances per GPU, frustum+cone%s, "
-                    "%s compaction" % (n_inst, per, n_pairs, "+hiz(4K)" if args.hiz else "",
+                    "%s compaction" % (n_inst, per, n_pairs,
+                                       ("+hiz(4K, %s projection)" % ("unflipped" if args.unflipped else "reference (flipped)")) if args.hiz else "",
                                        ["ordered", "wave-atomic", "block-atomic"][args.compaction]))
-        out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", value, elapsed, args.steps, name, extra_cfg)
+        out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", r["value"], r["elapsed"], r["steps"], name, extra_cfg)
+        out["scaling"] = r["scaling"]
         traffic, traffic_src = pmc_traffic(args, workload, n_inst, per)
         out["roofline"] = roofline(algo, k_ms, kernels, traffic, traffic_src,
-                                   kernel_ms_single_call=round(float(np.mean(kernel_ms)), 4),
-                                   bytes_per_pair=round(algo / (n_pairs * n_views), 2))
+                                   kernel_ms_single_call=round(r["kernel_ms"], 4),
+                                   bytes_per_pair=round(algo / max(n_pairs * n_views, 1), 2))
         if world == 1:
             out["roofline"]["measured_device_copy"] = measured_copy_gbs(device)
             out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / out["roofline"]["measured_device_copy"], 4)
-        if with_lists:
-            out["with_list_gather"] = with_lists
+        if r["with_lists"]:
+            out["with_list_gather"] = r["with_lists"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_cull(cone, sphere, xf, off, cnt, views[-1], tests, n_inst, per,
-                                                    None if depth is None else depth, hiz_size, workload)
+            cone, sphere, xf, off, cnt = r["scene"]
+            out["cpu_baseline"] = cpu_baseline_cull(cone, sphere, xf, off, cnt, r["views"][-1], r["tests"], n_inst, per,
+                                                    r["depth"], r["hiz_size"], workload)
+    if world > 1 and args.scaling == "weak" and not args.no_strong_leg:
+        # the same job as BASELINE words config 4: ONE scene split over the ranks.  Reported beside the
+        # weak-scaling value in the same line (the default `value` stays weak: fixed work per GPU).
+        r.pop("scene")  # release the weak leg's scene before the second one is generated
+        r2 = cull_leg(env, workload, "strong", steps=min(args.steps, 50), warmup=min(args.warmup, 5), gather_lists=args.gather_lists)
+        if rank == 0:
+            out["strong_scaling"] = {"value": round(r2["value"], 3), "unit": "G/s", "ms_per_step": round(r2["elapsed"] / r2["steps"] * 1e3, 4),
+                                     "steps": r2["steps"], "meshlet_instances_total": r2["job_pairs"] * r2["n_views"],
+                                     "meshlet_instances_per_gpu": r2["n_pairs"] * r2["n_views"],
+                                     "kernel_ms_single_call": round(r2["kernel_ms"], 4),
+                                     "visible_fraction": round(r2["job_visible"] / max(r2["job_pairs"], 1), 4),
+                                     "with_list_gather": r2["with_lists"]}
+    if rank == 0:
         env.line(out)
 
 
@@ -815,16 +968,48 @@ def run_meshbuild(env):
         env.line(out)
 
 
+def run_rendezvous(args):
+    """The multi-rank control flow alone, on the CPU over gloo (no GPU, no library): rendezvous, one
+    all-reduce, rank 0 prints one JSON line.  Exists so that the launcher path of `--gpus N` can be tested
+    where there is no GPU.  MCULL_BENCH_FAIL_RANK=r makes rank r exit with status 3 after the rendezvous."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    first, n = shard_range(781250, world, rank)
+    t = torch.tensor([n, 1 << rank], dtype=torch.int64)
+    if world > 1:
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.all_reduce(t)
+    if os.environ.get("MCULL_BENCH_FAIL_RANK") == str(rank):
+        os._exit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "rendezvous", "n_gpus": world, "instances": int(t[0]), "ranks_seen": int(t[1])}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="config4", choices=["config4", "config1", "config3", "config5", "hiz", "bounds", "depth", "meshbuild"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config1", "config3", "config5", "hiz", "bounds", "depth", "meshbuild", "rendezvous"])
     ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
     ap.add_argument("--meshlets-per-instance", type=int, default=0)
     ap.add_argument("--compaction", type=int, default=0, help="0 ordered, 1 wave atomic, 2 block atomic")
     ap.add_argument("--hiz", action="store_true", help="config4: also run the Hi-Z test against a 4K pyramid")
+    ap.add_argument("--unflipped", action="store_true",
+                    help="config4: projection without the reference's y flip, so that the Hi-Z test selects real mip levels")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="cull workloads with N ranks: weak = one whole scene per GPU (value = N scenes per step); strong = one "
+                         "scene split into N contiguous instance shards (BASELINE config 4 as worded)")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="multi-rank weak runs also measure the strong-scaling form and report it as `strong_scaling`; this skips it")
     ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
     ap.add_argument("--depth-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"))
     ap.add_argument("--separate-views", action="store_true", help="config5: one cull call per view instead of one fused pass")
@@ -840,6 +1025,11 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="control-flow rehearsal only: all ranks share GPU 0, collectives over gloo on host copies")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks here, as fresh child processes, before anything touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.workload == "rendezvous":
+        sys.exit(run_rendezvous(args))
     env = Env(args)
     if args.workload == "hiz":
         run_hiz(env)

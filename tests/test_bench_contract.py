@@ -56,3 +56,73 @@ def test_bench_command_line_keeps_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--workload"):
         assert flag in out.stdout
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run_bench(argv, env=None):
+    full = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        full.pop(k, None)
+    full.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300, env=full)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: N child ranks rendezvous over gloo
+    (the CPU-only workload), stdout carries exactly rank 0's JSON line, exit status 0."""
+    out = _run_bench(["--gpus", str(world), "--workload", "rendezvous"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["ranks_seen"] == (1 << world) - 1
+    assert j["instances"] == 781250, "the contiguous shards of all ranks cover the scene exactly once"
+
+
+def test_a_failing_rank_fails_the_launcher():
+    out = _run_bench(["--gpus", "2", "--workload", "rendezvous"], env={"MCULL_BENCH_FAIL_RANK": "1"})
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+
+
+def test_under_a_launcher_no_ranks_are_spawned():
+    """With WORLD_SIZE set (torch.distributed.run, the driver's way) the process is a rank, not a launcher."""
+    port = _bench_module().free_port()
+    out = _run_bench(["--gpus", "1", "--workload", "rendezvous"],
+                     env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert out.returncode == 0 and json.loads(out.stdout.strip())["n_gpus"] == 1
+    bad = _run_bench(["--gpus", "2", "--workload", "rendezvous"],
+                     env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert bad.returncode != 0 and "does not match WORLD_SIZE" in bad.stderr
+
+
+def test_strong_scaling_shards_concatenate_to_the_single_rank_scene():
+    """The counter-based scene generator: the shards ranks generate locally equal slices of the scene one
+    rank generates (checked on the CPU generator; ragged shard boundaries inside generator chunks)."""
+    import torch
+
+    b = _bench_module()
+    n, per = 3 * b.SCENE_CHUNK + 217, 8
+    whole = b.make_scene_range("cpu", 0, n, per, seed=42)
+    for world in (1, 2, 3, 8):
+        cuts = [b.shard_range(n, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and sum(c[1] for c in cuts) == n
+        assert all(cuts[r][0] + cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+        parts = [b.make_scene_range("cpu", f, k, per, seed=42) for f, k in cuts]
+        for i in range(3):
+            assert torch.equal(torch.cat([p[i] for p in parts]), whole[i])
+    other = b.make_scene_range("cpu", 0, n, per, seed=43)
+    assert not torch.equal(other[0], whole[0])
+    # unit axes, coneW in [0, 1] with a share pinned to 1, radii in [0.01, 0.05]
+    axis_len = whole[0][:, :3].norm(dim=1)
+    assert torch.allclose(axis_len, torch.ones_like(axis_len), atol=1e-5)
+    assert 0.05 < float((whole[0][:, 3] == 1.0).float().mean()) < 0.15
+    assert float(whole[1][:, 3].min()) >= 0.01 and float(whole[1][:, 3].max()) <= 0.05
