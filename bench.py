@@ -618,7 +618,7 @@ def pmc_traffic(args, workload, n_inst, per):
     """Traffic of one step of the profiled default workload, or None when the workload differs."""
     if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False):
         return None, None
-    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "super_sum_kernel", "compact_kernel", "emit_commands_kernel"))
+    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "super_sum_kernel", "scan_tiles_kernel", "compact_kernel", "emit_commands_kernel"))
 
 
 def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):

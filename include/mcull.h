@@ -251,7 +251,8 @@ int mcull_hiz_download_level(mcull_ctx *ctx, uint32_t view, uint32_t level, floa
  * (instance, meshlet) pair, compacts the survivors into one global visible list and
  * writes one indirect command per instance (createIndirectBuffer, Engine.cpp:1466-1484,
  * made dynamic).  `params` may be NULL (all tests, ordered compaction, 8-byte commands).
- * Returns MCULL_E_CAPACITY only from the download/count calls, never asynchronously. */
+ * Returns MCULL_E_CAPACITY only from the download/count calls, never asynchronously (list larger than its
+ * capacity, or 2^32 visible pairs and more: see mcull_download_count). */
 int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
                mcull_cull_result *result);
 
@@ -268,7 +269,7 @@ int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_pa
  * download / rebase / payload / rasterise calls refer to) is left untouched. */
 #define MCULL_STATIC_MAX_GROUPS 2097152ull
 #define MCULL_STATIC_MAX_INSTANCES 1048576ull
-#define MCULL_STATIC_SCRATCH_BYTES 21005056ull
+#define MCULL_STATIC_SCRATCH_BYTES 21070592ull
 int mcull_cull_static(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_params *params,
                       mcull_cull_result *result);
 
@@ -309,7 +310,11 @@ int mcull_rebase_commands(mcull_ctx *ctx, const uint64_t *device_totals, uint32_
 uint64_t mcull_task_payload_count(const mcull_ctx *ctx);
 int mcull_emit_task_payloads(mcull_ctx *ctx, mcull_task_payload *out);
 
-/* Synchronous read-backs of the last mcull_cull. */
+/* Synchronous read-backs of the last mcull_cull.  firstTask and the list offsets behind it are 32-bit
+ * (the NV record's field width): when an ordered cull keeps 2^32 pairs or more, all three calls return
+ * MCULL_E_CAPACITY (mcull_download_count still stores the exact 64-bit count in *total) instead of
+ * handing out wrapped offsets; split such a scene over several culls or GPUs.  A caller that consumes the
+ * buffers on the device without these calls (mcull_cull_static, graph replay) checks *result.total itself. */
 int mcull_download_count(mcull_ctx *ctx, uint64_t *total);
 /* MCULL_E_CAPACITY (and *total = required entries) when the list did not fit. */
 int mcull_download_list(mcull_ctx *ctx, mcull_visible *out, uint64_t capacity, uint64_t *total);

@@ -279,7 +279,7 @@ def test_config4_full_size(mc, O, H):
     bench = importlib.import_module("bench")
     dev = torch.device("cuda", 0)
     n_inst, per = 781250, 128
-    cone, sphere, xf = bench.make_scene(dev, n_inst, per, seed=42)
+    cone, sphere, xf = bench.make_scene_range(dev, 0, n_inst, per, seed=42)
     torch.cuda.synchronize()
     off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
     cnt = np.full(n_inst, per, dtype="<u4")
@@ -322,3 +322,39 @@ def test_config4_full_size(mc, O, H):
         assert (got[:, 0] == i).all() and np.array_equal(got[:, 1] - i * per, want["meshletID"] - k * per)
         pos += n
     c.close()
+
+
+def test_2_pow_32_visible_pairs_are_reported_not_wrapped(mc, H):
+    """Config 3's shape with nothing culled: 1 M instances x 13 916 meshlets = 13.9 G visible pairs.  firstTask is
+    a 32-bit field, so the commands of such a cull have wrapped: every download call says so with
+    MCULL_E_CAPACITY and the exact 64-bit count, instead of handing out offsets modulo 2^32.  The list
+    capacity is 1000 entries, so nothing large is written."""
+    n_inst, per = 1_000_000, 13916
+    cone, sphere = H.synthetic_bounds(per, seed=5)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    xf = torch.zeros((n_inst, 16), device=dev)
+    xf[:, 0] = xf[:, 5] = xf[:, 10] = xf[:, 15] = 1.0
+    xf[:, 12:15] = torch.rand((n_inst, 3), device=dev, generator=gen) * 100
+    torch.cuda.synchronize()
+    with mc.Context(0) as c:
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
+        g = H.create_globals(meshlet_count=per)
+        r = c.cull(g, tests=0, list_capacity=1000)
+        assert r.n_pairs == n_inst * per
+        with pytest.raises(mc.McullError) as e:
+            c.download_count()
+        assert e.value.status == mc.E_CAPACITY and e.value.count == n_inst * per and "wrapped" in str(e.value)
+        with pytest.raises(mc.McullError) as e:
+            c.download_commands(n_inst)
+        assert e.value.status == mc.E_CAPACITY
+        with pytest.raises(mc.McullError) as e:
+            c.download_list(capacity=1000)
+        assert e.value.status == mc.E_CAPACITY
+        # the same scene below the limit still downloads: 300 000 instances = 4.17 G pairs < 2^32
+        c.upload_transforms(xf.data_ptr(), count=300_000, mem=mc.MEM_DEVICE)
+        c.cull(g, tests=0, list_capacity=1000)
+        assert c.download_count() == 300_000 * per
+        cmds = c.download_commands(300_000).view(mc.CMD)
+        assert int(cmds["taskCount"][0]) == per and int(cmds["firstTask"][-1]) == (300_000 - 1) * per

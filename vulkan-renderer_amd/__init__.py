@@ -48,7 +48,7 @@ COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
 CMD_NV_MESHLETS, CMD_EXT_GROUPS = 0, 1
 CMD_EXT = np.dtype([("groupCountX", "<u4"), ("groupCountY", "<u4"), ("groupCountZ", "<u4")])
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
-STATIC_MAX_GROUPS, STATIC_MAX_INSTANCES, STATIC_SCRATCH_BYTES = 2097152, 1048576, 21005056
+STATIC_MAX_GROUPS, STATIC_MAX_INSTANCES, STATIC_SCRATCH_BYTES = 2097152, 1048576, 21070592
 
 # every symbol include/mcull.h declares
 ABI_SYMBOLS = [
@@ -583,7 +583,12 @@ class Context:
 
     def download_count(self):
         n = _U64()
-        self._chk(lib.mcull_download_count(self._h, C.byref(n)))
+        rc = lib.mcull_download_count(self._h, C.byref(n))
+        if rc == E_CAPACITY:  # 2^32 visible pairs or more: the exact count travels with the error
+            err = McullError(rc, lib.mcull_last_error(self._h).decode())
+            err.count = int(n.value)
+            raise err
+        self._chk(rc)
         return int(n.value)
 
     def download_list(self, capacity=None):

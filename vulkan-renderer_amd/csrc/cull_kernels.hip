@@ -11,7 +11,9 @@
 //
 // Compaction strategies:
 //   ordered      cull_mask_kernel  -> one 64-bit ballot word per group + one count per 256-group tile
-//                scan_tiles_kernel -> exclusive prefix of the tile counts (+ the total)
+//                scan_tiles_kernel -> (scenes above 1024 tiles) exclusive 64-bit prefix of the tile counts + the
+//                                     total, one workgroup; smaller scenes sum the lower counters inside the
+//                                     scatter pass instead of paying a launch
 //                compact_kernel    -> per-tile block scan + scatter; list sorted by (drawID, meshletID)
 //                emit_commands_kernel -> {taskCount, firstTask} per instance
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
@@ -26,7 +28,9 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kTileGroups = 256;  // groups per compaction tile = 16384 meshlet-instances
 constexpr uint32_t kRoundGroups = 64;   // groups staged in LDS per output round of the scatter pass (32 KiB)
-constexpr uint32_t kSuperTiles = 256;  // tiles per super-tile (second level of the offset sums)
+constexpr uint32_t kScanMinTiles = 1024;  // scenes with more tiles get their tile offsets from scan_tiles_kernel
+constexpr int kScanBlock = 1024;          // threads of that kernel's single workgroup
+constexpr int kScanPerThread = 8;         // consecutive counters per thread and iteration
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax * bx + ay * by) + az * bz;
@@ -563,32 +567,70 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 }
 
 // ------------------------------------------------------------------------------------------------
-// Scenes with more than kSuperTiles * 4 tiles: sum of each run of kSuperTiles tile counters, so
-// that the scatter pass reads at most n_tiles/256 + 255 counters per workgroup instead of n_tiles.
-__global__ __launch_bounds__(kBlock) void super_sum_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
-                                                           uint32_t *__restrict__ super_counts) {
-    __shared__ uint32_t s_sum[kWaves];
-    const uint32_t j = blockIdx.x * kSuperTiles + threadIdx.x;
-    uint32_t x = j < n_tiles ? tile_counts[j] : 0u;
+// Scenes with more than kScanMinTiles tiles: the list offset of every tile (exclusive 64-bit prefix of the
+// tile counters) and the total, by ONE workgroup that walks the counters 8192 at a time with a running
+// carry (6 104 counters for 100 M pairs: one iteration; 851 000 for 13.9 G pairs: 104).  The scatter pass
+// then starts each tile with one load instead of summing the lower counters itself.
+__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
+                                                                unsigned long long *__restrict__ tile_offsets,
+                                                                unsigned long long *__restrict__ total) {
+    constexpr int kScanWaves = kScanBlock / 64;
+    __shared__ unsigned long long s_wave[kScanWaves];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += kScanBlock * kScanPerThread) {
+        const uint32_t j0 = base + threadIdx.x * kScanPerThread;
+        uint32_t x[kScanPerThread];
+        if (j0 + kScanPerThread <= n_tiles) {  // counters are 256-byte aligned and j0 is a multiple of 8
+            const uint4 lo = *reinterpret_cast<const uint4 *>(tile_counts + j0);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(tile_counts + j0 + 4);
+            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+        } else {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) super_counts[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+            for (int k = 0; k < kScanPerThread; k++) x[k] = j0 + k < n_tiles ? tile_counts[j0 + k] : 0u;
+        }
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) sum += x[k];
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned long long wave_base = 0, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < kScanWaves; w++) {
+            const unsigned long long t = s_wave[w];
+            if ((uint32_t)w < wave) wave_base += t;
+            chunk += t;
+        }
+        unsigned long long off = carry + wave_base + incl - sum;
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) {
+            if (j0 + k < n_tiles) tile_offsets[j0 + k] = off;
+            off += x[k];
+        }
+        carry += chunk;
+        __syncthreads();  // s_wave is rewritten by the next iteration
+    }
+    if (threadIdx.x == 0) *total = carry;
 }
 
 // ------------------------------------------------------------------------------------------------
 // ordered, pass 2: scatter.  `split` workgroups per 256-group tile (each redoes the tile's scan and
-// writes the entries of 256/split consecutive groups; the launcher uses 1, larger values exist for
-// the design-evidence benchmark).  A tile's list offset is the number of
-// visible pairs in all lower tiles: the sum of the lower tile counters (read from L2), or, for
-// very large scenes, of the lower super-tile sums plus the lower counters of its own super-tile.  Then one group per
+// writes the entries of 256/split consecutive groups; the launcher uses 1 except for very small scenes).
+// A tile's list offset is the number of visible pairs in all lower tiles: read from tile_offsets
+// (scan_tiles_kernel, which has also written the total) or, for scenes of at most kScanMinTiles tiles,
+// summed here from the lower tile counters (read from L2).  Then one group per
 // thread for the in-tile scan, and one group per wave-iteration for the stores (lane l owns bit l,
 // the slots of a group are contiguous).
 template <bool NT>
 __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
-    const uint32_t *__restrict__ super_counts, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
+    const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
     unsigned long long *__restrict__ total, uint32_t split) {
     __shared__ uint64_t s_word[kBlock];
@@ -600,21 +642,19 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile_idx = blockIdx.x / split, part_idx = blockIdx.x - tile_idx * split;
     const uint32_t round_span = kTileGroups / split;  // groups whose entries this workgroup writes
-    unsigned long long part = 0;
-    if (super_counts) {
-        const uint32_t super = tile_idx / kSuperTiles;
-        for (uint32_t j = threadIdx.x; j < super; j += kBlock) part += super_counts[j];
-        const uint32_t j = super * kSuperTiles + threadIdx.x;  // kSuperTiles == kBlock
-        if (j < tile_idx) part += tile_counts[j];
+    unsigned long long running;
+    if (tile_offsets) {
+        running = tile_offsets[tile_idx];  // uniform: one scalar load
     } else {
+        unsigned long long part = 0;
         for (uint32_t j = threadIdx.x; j < tile_idx; j += kBlock) part += tile_counts[j];
-    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-    if (lane == 0) s_sum[wave] = part;
-    __syncthreads();
-    const unsigned long long running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + tile_counts[tile_idx];
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_sum[wave] = part;
+        __syncthreads();
+        running = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = running + tile_counts[tile_idx];
+    }
     const uint32_t tile = tile_idx * kTileGroups;
     const uint32_t g_end = min(tile + kTileGroups, n_groups);
     const uint32_t g = tile + threadIdx.x;
@@ -855,9 +895,8 @@ uint32_t tile_count_for(uint64_t n_groups) { return (uint32_t)((n_groups + kTile
         default: { constexpr uint32_t T = 7; CALL; break; }                      \
     }
 
-uint32_t super_count_for(uint64_t n_groups) { return (tile_count_for(n_groups) + kSuperTiles - 1) / kSuperTiles; }
-// from 1024 tiles on (16.8 M pairs) the second level pays for its launch: 100 M pairs 0.571 ms against 0.574 ms
-bool needs_super_counts(uint64_t n_groups) { return tile_count_for(n_groups) > kSuperTiles * 4u; }
+// above 1024 tiles (16.8 M pairs) the scan launch pays for itself
+bool needs_tile_offsets(uint64_t n_groups) { return tile_count_for(n_groups) > kScanMinTiles; }
 
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
@@ -920,9 +959,9 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
     return hipGetLastError();
 }
 
-// super_counts may be nullptr (scenes up to kSuperTiles * 4 tiles)
+// tile_offsets (one uint64 per tile) may be nullptr for scenes up to kScanMinTiles tiles
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
-                          uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
+                          uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st) {
     const uint32_t tiles = tile_count_for(s.n_groups);
     // One workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
@@ -931,18 +970,19 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
     // staging round each, halve the pass (the reference's scene, 20 tiles: 5.5 us against 10.4 us).
     const uint32_t split = tiles <= 64u ? 4u : tiles <= 128u ? 2u : 1u;
     const uint32_t grid = tiles * split;
-    if (super_counts) {
-        hipLaunchKernelGGL(super_sum_kernel, dim3(super_count_for(s.n_groups)), dim3(kBlock), 0, st, tile_counts, tiles,
-                           super_counts);
+    const unsigned long long *offs = (const unsigned long long *)tile_offsets;
+    if (tile_offsets) {
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanBlock), 0, st, tile_counts, tiles,
+                           (unsigned long long *)tile_offsets, (unsigned long long *)total);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (streaming)
-        hipLaunchKernelGGL(compact_kernel<true>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, super_counts,
+        hipLaunchKernelGGL(compact_kernel<true>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
                            (unsigned long long *)total, split);
     else
-        hipLaunchKernelGGL(compact_kernel<false>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, super_counts,
+        hipLaunchKernelGGL(compact_kernel<false>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
                            (unsigned long long *)total, split);
     return hipGetLastError();

@@ -34,7 +34,7 @@ struct HizSlot {
 }  // namespace
 
 // Scratch of mcull_cull_static, the entry point that allocates nothing: the visibility ballots, the tile
-// counters and their second level, and the per-instance list offsets of one ordered cull of at most
+// counters and their exclusive prefix, and the per-instance list offsets of one ordered cull of at most
 // MCULL_STATIC_MAX_GROUPS groups and MCULL_STATIC_MAX_INSTANCES instances.  Every GPU the library runs on holds
 // its own copy of this array until the process ends.  Host code never uses the array's name as an address:
 // mcull_create asks the runtime for the copy's device address once per device (scratch_address) and every
@@ -42,13 +42,13 @@ struct HizSlot {
 namespace {
 constexpr size_t kStaticMaskBytes = (size_t)MCULL_STATIC_MAX_GROUPS * 8;
 constexpr size_t kStaticTileBytes = ((size_t)MCULL_STATIC_MAX_GROUPS / 256 + 1) * 4;      // one counter per 256 groups
-constexpr size_t kStaticSuperBytes = ((size_t)MCULL_STATIC_MAX_GROUPS / 65536 + 1) * 4;   // one sum per 256 counters
+constexpr size_t kStaticOffsetsBytes = ((size_t)MCULL_STATIC_MAX_GROUPS / 256 + 1) * 8;     // one 64-bit list offset per tile
 constexpr size_t kStaticFirstBytes = ((size_t)MCULL_STATIC_MAX_INSTANCES + 1) * 4;
 constexpr size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 constexpr size_t kStaticMaskOff = 0;
 constexpr size_t kStaticTileOff = kStaticMaskOff + align256(kStaticMaskBytes);
-constexpr size_t kStaticSuperOff = kStaticTileOff + align256(kStaticTileBytes);
-constexpr size_t kStaticFirstOff = kStaticSuperOff + align256(kStaticSuperBytes);
+constexpr size_t kStaticOffsetsOff = kStaticTileOff + align256(kStaticTileBytes);
+constexpr size_t kStaticFirstOff = kStaticOffsetsOff + align256(kStaticOffsetsBytes);
 constexpr size_t kStaticBytes = kStaticFirstOff + align256(kStaticFirstBytes);
 static_assert(kStaticBytes == MCULL_STATIC_SCRATCH_BYTES, "mcull.h states the size of the static scratch");
 }  // namespace
@@ -119,9 +119,9 @@ struct mcull_ctx {
         uint64_t n_pairs = 0;
     };
     struct ViewOut {
-        DevBuf mask, tile_counts, super_counts, inst_first, inst_count, total, list, commands;
+        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands;
         uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
-        bool counters_clean = false;   // tile/super counters are all zero (the mask pass adds into them, the command pass re-zeroes)
+        bool counters_clean = false;   // tile counters are all zero (the mask pass adds into them, the command pass re-zeroes)
         uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
         Last last;                      // description of the last cull (for rebase / downloads / payloads)
     } out[MCULL_MAX_VIEWS];
@@ -324,7 +324,7 @@ int mcull_destroy(mcull_ctx *c) {
                       &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
-        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.super_counts, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
+        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
             release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -697,7 +697,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
     plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
-    plan->two_level = mcull::needs_super_counts(s.n_groups);
+    plan->two_level = mcull::needs_tile_offsets(s.n_groups);
     // bounds that cannot stay cache-resident between culls are read with the streaming hint
     plan->streaming = c->force_streaming || c->n_meshlets * 32ull > (64ull << 20);
     return MCULL_OK;
@@ -737,7 +737,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     } else {
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
         if ((rc = ensure(c, o.tile_counts, (size_t)plan->n_tiles * 4))) return rc;
-        if (plan->two_level && (rc = ensure(c, o.super_counts, (size_t)mcull::super_count_for(s.n_groups) * 4))) return rc;
+        if (plan->two_level && (rc = ensure(c, o.tile_offsets, (size_t)plan->n_tiles * 8))) return rc;
         if ((rc = ensure(c, o.inst_first, (c->n_instances + 1) * 4))) return rc;
         if (!o.counters_clean) HIPCHK(c, hipMemsetAsync(o.tile_counts.p, 0, o.tile_counts.cap, c->stream));
         o.counters_clean = false;  // until the command kernel that re-zeroes them has been enqueued
@@ -748,7 +748,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
 // scatter + commands of the ordered path (after the mask pass has filled mask and tile counters)
 int launch_ordered_tail(mcull_ctx *c, mcull_ctx::ViewOut &o, const CullPlan &pl) {
     HIPCHK(c, mcull::launch_compact(pl.s, (const uint64_t *)o.mask.p, (const uint32_t *)o.tile_counts.p,
-                                    pl.two_level ? (uint32_t *)o.super_counts.p : nullptr, pl.list, pl.capacity,
+                                    pl.two_level ? (uint64_t *)o.tile_offsets.p : nullptr, pl.list, pl.capacity,
                                     (uint32_t *)o.inst_first.p, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
     HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, (const uint32_t *)o.inst_first.p, nullptr,
                                           (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands,
@@ -867,7 +867,7 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
     if (!ptr) return fail(c, MCULL_E_STATE, "the static scratch of device %d was never resolved", c->device);
     uint64_t *mask = reinterpret_cast<uint64_t *>(ptr + kStaticMaskOff);
     uint32_t *tile_counts = reinterpret_cast<uint32_t *>(ptr + kStaticTileOff);
-    uint32_t *super_counts = reinterpret_cast<uint32_t *>(ptr + kStaticSuperOff);
+    uint64_t *tile_offsets = reinterpret_cast<uint64_t *>(ptr + kStaticOffsetsOff);
     uint32_t *inst_first = reinterpret_cast<uint32_t *>(ptr + kStaticFirstOff);
     pl.total = params->total;
     pl.list = params->list;
@@ -884,7 +884,7 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
         // counters the mask pass adds into start at zero
         HIPCHK(c, hipMemsetAsync(tile_counts, 0, (size_t)pl.n_tiles * 4, c->stream));
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, mask, tile_counts, pl.streaming, c->stream, nullptr));
-        HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? super_counts : nullptr, pl.list, pl.capacity,
+        HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? tile_offsets : nullptr, pl.list, pl.capacity,
                                         inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, inst_first, nullptr, (const uint64_t *)pl.total, nullptr, 0,
                                               pl.lay, pl.commands, tile_counts, c->stream));
@@ -1029,6 +1029,11 @@ int mcull_download_count(mcull_ctx *c, uint64_t *total) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(total, o.total_ptr, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // firstTask and the per-instance list offsets are 32-bit fields (VkDrawMeshTasksIndirectCommandNV): an
+    // ordered cull that keeps 2^32 pairs or more has wrapped them, whatever the list capacity was
+    if (o.last.compaction == MCULL_COMPACT_ORDERED && *total > 0xffffffffull)
+        return fail(c, MCULL_E_CAPACITY, "%llu visible pairs: the 32-bit firstTask offsets of the commands have wrapped",
+                    (unsigned long long)*total);
     return MCULL_OK;
 }
 
@@ -1060,6 +1065,8 @@ int mcull_download_commands(mcull_ctx *c, void *out, uint64_t bytes) {
     const uint64_t have = (uint64_t)o.last.scene.n_instances * o.last.lay.stride;
     if (bytes > have) return fail(c, MCULL_E_INVALID, "requested %llu bytes of %llu", (unsigned long long)bytes, (unsigned long long)have);
     HIPCHK(c, hipSetDevice(c->device));
+    uint64_t n = 0;
+    if (int rc = mcull_download_count(c, &n)) return rc;  // MCULL_E_CAPACITY: the commands' firstTask values have wrapped
     if (bytes) {
         HIPCHK(c, hipMemcpyAsync(out, o.last.commands, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

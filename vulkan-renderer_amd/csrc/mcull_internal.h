@@ -50,8 +50,7 @@ struct CmdLayout {
 
 // ---- launchers (each returns the hipError_t of the launch) ----
 uint32_t tile_count_for(uint64_t n_groups);
-uint32_t super_count_for(uint64_t n_groups);
-bool needs_super_counts(uint64_t n_groups);
+bool needs_tile_offsets(uint64_t n_groups);  // the scatter pass wants one uint64 list offset per tile (scan_tiles_kernel)
 // One pass over the scene for n_views views (ordered path only): views[i] -> masks[i], tile_counts[i].
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st,
@@ -59,7 +58,7 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
-                          uint32_t *super_counts, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
+                          uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st);
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
