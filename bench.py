@@ -426,7 +426,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     cmds = [x[:n_inst] for x in cmds_packed]
     total = [x[n_rows:].view(torch.int64) for x in cmds_packed]
     # multi-view: the last view writes the buffers the collectives read; the others stay context-owned
-    view_params = [[dict(tests=tests, hiz_view=v) for v in range(n_views)] for _ in range(2)]
+    view_params = [[dict(tests=tests, hiz_view=v, precull=not args.no_precull) for v in range(n_views)] for _ in range(2)]
     for bb in range(2):
         view_params[bb][-1].update(list_ptr=lst.data_ptr(), list_capacity=cap, commands_ptr=cmds[bb].data_ptr(),
                                    total_ptr=total[bb].data_ptr())
@@ -460,10 +460,12 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                     if record:
                         ms += ctx.last_kernel_ms()
                 if args.ctx_outputs:
-                    ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, total_ptr=total[b].data_ptr())
+                    ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, total_ptr=total[b].data_ptr(),
+                             precull=not args.no_precull)
                 else:
                     ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
-                             list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr())
+                             list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr(),
+                             precull=not args.no_precull)
                 if record:
                     ms += ctx.last_kernel_ms()
         if multi:
@@ -513,6 +515,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                  commands_ptr=cmds[1].data_ptr(), total_ptr=total[1].data_ptr())
         env.fence()
         hiz_pairs = int(total[1].item())
+    pre_marked, pre_tested, pre_per_group = ctx.precull_stats()  # of the last timed cull (view slot 0)
     vis_views = None
     if workload == "config5" and not args.separate_views:
         vis_views = []
@@ -523,6 +526,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 kernel_ms=float(np.mean(kernel_ms)), visible=visible, job_visible=job_visible, with_lists=with_lists,
                 n_inst=n_inst, n_scene=n_scene, per=per, n_pairs=n_pairs, job_pairs=job_pairs, n_views=n_views, unique=unique,
                 tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
+                precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances"),
                 value=job_pairs * n_views / (elapsed / steps) / 1e9,
                 scene=(cone, sphere, xf, off, cnt))
 
@@ -546,6 +550,7 @@ def run_cull(env, workload):
             else ("one whole scene per GPU")
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / max(n_pairs, 1), 4),
                      **({"pairs_reaching_hiz": r["hiz_pairs"]} if r["hiz_pairs"] else {}),
+                     "instance_precull": r["precull"],
                      "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % shard_note)
                      if multi else "single GPU"}
         if workload == "config5":
@@ -1019,6 +1024,7 @@ def main():
                     help="milliseconds of untimed load before the warm-up steps (clock ramp after the idle set-up); 0 = off")
     ap.add_argument("--graph", action="store_true", help="config1: also replay the frame as one captured HIP graph")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
+    ap.add_argument("--no-precull", action="store_true", help="cull workloads: switch the instance-level pre-cull off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bounds-copies", type=int, default=64, help="bounds workload: copies of the kitten fixture")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")

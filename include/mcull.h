@@ -135,6 +135,18 @@ typedef struct mcull_task_payload {
 #define MCULL_CMD_NV_MESHLETS 0
 #define MCULL_CMD_EXT_GROUPS 1
 
+/* mcull_cull_params.flags.
+ * Ordered culls that run the frustum test first test ONE enclosing sphere per instance (of the
+ * instance's whole meshlet range, computed once after an upload) against the five planes, with a margin
+ * that covers the rounding of the per-meshlet expression; the groups of an instance that is certainly
+ * outside get zero ballots without a meshlet being loaded or tested.  Results are identical with and
+ * without it.  The reference has no such level: it launches every task group of every draw
+ * (Engine.cpp:1475-1483, shader.task:79-102).  MCULL_CULL_NO_INSTANCE_PRECULL switches it off
+ * (measurements, parity tests).  Bounds that were adopted in place (mcull_upload_bounds_soa with adopt)
+ * must be announced again with that call after their contents change: the range spheres are derived
+ * from them. */
+#define MCULL_CULL_NO_INSTANCE_PRECULL 1u
+
 /* VkDrawMeshTasksIndirectCommandEXT as written for MCULL_CMD_EXT_GROUPS. 12 bytes. */
 typedef struct mcull_mesh_tasks_cmd_ext {
     uint32_t groupCountX, groupCountY, groupCountZ;
@@ -148,7 +160,7 @@ typedef struct mcull_cull_params {
     uint32_t cmd_stride;     /* bytes between commands; 0 -> the record size (8 / 12)  */
     uint32_t cmd_offset;     /* byte offset of the command in a record; 28/20 = DrawIndirect */
     uint32_t write_mask;     /* non-zero: keep the 1-bit-per-pair visibility mask      */
-    uint32_t reserved;
+    uint32_t flags;          /* MCULL_CULL_* bits, 0 for the defaults                  */
     /* optional caller-owned device outputs (NULL -> context-owned buffers)            */
     mcull_visible *list;     /* capacity list_capacity entries                         */
     uint64_t list_capacity;
@@ -320,6 +332,13 @@ int mcull_download_count(mcull_ctx *ctx, uint64_t *total);
 int mcull_download_list(mcull_ctx *ctx, mcull_visible *out, uint64_t capacity, uint64_t *total);
 int mcull_download_commands(mcull_ctx *ctx, void *out, uint64_t bytes);
 int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
+
+/* What the instance pre-cull of the last cull removed (synchronous; one small counting kernel, run on
+ * request only).  *marked = instances marked as certainly outside the frustum (scenes without instance
+ * ranges) or 64-meshlet groups of such instances (scenes with ranges: *per_group != 0); *tested = how many
+ * instances / groups there were.  0 / 0 when the pre-cull did not run (frustum test off, switched off,
+ * scene below 2048 groups, unordered compaction).  No reference counterpart. */
+int mcull_precull_stats(mcull_ctx *ctx, uint64_t *marked, uint64_t *tested, int *per_group);
 
 /* Device timestamps around the kernels of each mcull_cull / mcull_hiz_build /
  * mcull_compute_bounds (HIP events on the context's stream; the reference's timestamp

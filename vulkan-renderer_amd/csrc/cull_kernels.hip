@@ -332,6 +332,248 @@ __device__ __forceinline__ void store_entry(mcull_visible *__restrict__ list, un
     else reinterpret_cast<unsigned long long *>(list)[slot] = e;
 }
 
+// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
+// prefix and writes the workgroup total to *total_out (uniform).
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s_wave /*[kWaves]*/, uint32_t *total_out) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+        const uint32_t t = s_wave[w];
+        if ((uint32_t)w < wave) wave_base += t;
+        total += t;
+    }
+    *total_out = total;
+    __syncthreads();  // s_wave may be reused by the caller's next scan
+    return wave_base + incl - x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Instance-level pre-cull (no counterpart in the reference, which launches every task group of every
+// draw, Engine.cpp:1475-1483).  Each meshlet range gets one enclosing sphere in mesh space; a cull first
+// tests every instance's sphere against the five planes and marks the instances that are certainly
+// outside, and the mask pass then writes zero ballots for their groups without loading or testing a
+// single meshlet.  "Certainly" covers the rounding of the per-meshlet expression, so the ballots are
+// identical to those of the full evaluation (see instance_outside).
+
+// Enclosing sphere {C.xyz, R} of the meshlet spheres of one range: C = mean of the centres,
+// R >= max(|c_m - C| + r_m) (rounded up).  One workgroup per range.  A non-finite centre or radius
+// anywhere in the range, or a range above 2^20 meshlets (one workgroup would take too long), gives
+// R = +inf: such a range is never pre-culled.
+__global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__restrict__ centre_radius,
+                                                              const uint2 *__restrict__ ranges, uint32_t uniform_count,
+                                                              float4 *__restrict__ spheres) {
+    __shared__ float s_red[kWaves][4];
+    const uint32_t i = blockIdx.x;
+    const uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (count == 0u || count > (1u << 20)) {
+        if (threadIdx.x == 0) spheres[i] = make_float4(0.0f, 0.0f, 0.0f, count ? __builtin_inff() : 0.0f);
+        return;
+    }
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, bad = 0.0f;
+    for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
+        const float4 c = centre_radius[first + j];
+        sx += c.x; sy += c.y; sz += c.z;
+        if (!(fabsf(c.x) < 1.0e18f && fabsf(c.y) < 1.0e18f && fabsf(c.z) < 1.0e18f && fabsf(c.w) < 1.0e18f)) bad = 1.0f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sx += __shfl_xor(sx, d, 64); sy += __shfl_xor(sy, d, 64); sz += __shfl_xor(sz, d, 64);
+        bad = fmaxf(bad, __shfl_xor(bad, d, 64));
+    }
+    if (lane == 0) { s_red[wave][0] = sx; s_red[wave][1] = sy; s_red[wave][2] = sz; s_red[wave][3] = bad; }
+    __syncthreads();
+    const float inv = 1.0f / (float)count;
+    const float cx = ((s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0])) * inv;
+    const float cy = ((s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1])) * inv;
+    const float cz = ((s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2])) * inv;
+    bad = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+    __syncthreads();
+    // any point works as the centre; what must hold is the radius, measured from the centre as stored
+    float r = 0.0f;
+    for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
+        const float4 c = centre_radius[first + j];
+        const float dx = c.x - cx, dy = c.y - cy, dz = c.z - cz;
+        // |c - C| + r, each step rounded to nearest: the factor below covers those roundings
+        r = fmaxf(r, sqrtf((dx * dx + dy * dy) + dz * dz) + fabsf(c.w));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) r = fmaxf(r, __shfl_xor(r, d, 64));
+    if (lane == 0) s_red[wave][0] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+        r = r * 1.00001f + 1.0e-30f;
+        if (bad != 0.0f || !(r < 1.0e18f)) r = __builtin_inff();
+        spheres[i] = make_float4(cx, cy, cz, r);
+    }
+}
+
+// instance_outside: is the instance certainly outside one of the five planes?
+// For every meshlet m of the instance the per-pair test evaluates, in binary32,
+//     e_m = (dot(n, M c_m + t) + d) + r_m |M col 0|          (frustumCull, shader.task:43-56)
+// and culls when e_m < 0 for some plane.  In real numbers e_m <= dot(n, M C + t) + d + max(|n|, 1) F R,
+// where F bounds the largest singular value of M's linear part (and |col 0|) from above and
+// R is the range's radius.  The binary32 evaluation of e_m differs from its real value by at most a few
+// units of roundoff times A = sum_j |n_j| (sum_k |M_jk| (|C_k| + R) + |t_j|) + |d| + F R; so does the
+// evaluation of the bound here.  The instance is marked only when  bound + 2^-16 A < 0, a margin 500
+// times the worst case of both.  Any NaN or infinity among the inputs makes A or the bound non-finite
+// and the comparison false, so such instances go through the per-meshlet path like the oracle's.
+// What was tried for handing the verdicts to the mask pass (100 M pairs, 32 % of the instances outside, mask
+// pass 484 us without any of it): one byte per group, the pass branching around a marked group's loads and
+// tests - 433 us, and 513 us when nothing is marked; a list cut into segments of 2048 groups with static
+// workgroup-to-segment mapping (ordered, no reservation) - 420 us, the workgroups behind a segment's count
+// still start and leave; one compacted list with one reservation per workgroup of the pre-pass - 392 us,
+// kept.  In each form the pre-pass itself takes 13 - 44 us.
+struct PreView {
+    float frustum[5][4];
+};
+constexpr uint32_t kWorkHeader = 64;  // uint32 words in front of a work list: [0] = number of entries (256-byte header)
+constexpr int kPreItems = 2;          // instances per thread of the pre-pass (one list reservation per 512 instances)
+
+// Layout of a work list over `units` entries: header, then `units` uint32 (ranged scenes: the group's index
+// in the scene; uniform scenes: the surviving instance's index), then - ranged scenes only - `units` uint4
+// group records {instance, first meshlet, count, local group}, 16-byte aligned, so that the mask pass gets a
+// listed group's record with one load instead of two dependent ones.
+__host__ __device__ inline size_t work_rec_offset_words(uint64_t units) { return (kWorkHeader + units + 3) & ~size_t(3); }
+
+__device__ __forceinline__ bool instance_outside(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+                                                 uint32_t per_instance_sphere, uint32_t i, const PreView &pv,
+                                                 const ViewConst *__restrict__ view_dev) {
+    const float4 *t = transforms + (size_t)i * 4;
+    const float4 c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
+    const float4 sp = spheres[per_instance_sphere ? i : 0u];
+    const float R = sp.w;
+    const float wx = ((c0.x * sp.x + c1.x * sp.y) + c2.x * sp.z) + c3.x;
+    const float wy = ((c0.y * sp.x + c1.y * sp.y) + c2.y * sp.z) + c3.y;
+    const float wz = ((c0.z * sp.x + c1.z * sp.y) + c2.z * sp.z) + c3.z;
+    // F >= the largest singular value of M's linear part: Gershgorin's bound on the largest eigenvalue of
+    // G = M^T M (max row sum of |G|), exact for the usual rotation x uniform scale (G diagonal), where it is
+    // also |col 0|; never below |col 0| (G_00 is part of row 0's sum)
+    const float g00 = (c0.x * c0.x + c0.y * c0.y) + c0.z * c0.z, g11 = (c1.x * c1.x + c1.y * c1.y) + c1.z * c1.z;
+    const float g22 = (c2.x * c2.x + c2.y * c2.y) + c2.z * c2.z;
+    const float g01 = fabsf((c0.x * c1.x + c0.y * c1.y) + c0.z * c1.z), g02 = fabsf((c0.x * c2.x + c0.y * c2.y) + c0.z * c2.z);
+    const float g12 = fabsf((c1.x * c2.x + c1.y * c2.y) + c1.z * c2.z);
+    // the products and sums above carry a few units of roundoff relative to |col i||col j| <= the trace
+    const float slack = ((g00 + g11) + g22) * 1.0e-6f;
+    const float F = sqrtf(fmaxf(fmaxf((g00 + g01) + g02, (g01 + g11) + g12), (g02 + g12) + g22) + slack) * 1.00001f;
+    const float ex = fabsf(sp.x) + R, ey = fabsf(sp.y) + R, ez = fabsf(sp.z) + R;
+    const float ax = ((fabsf(c0.x) * ex + fabsf(c1.x) * ey) + fabsf(c2.x) * ez) + fabsf(c3.x);
+    const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
+    const float az = ((fabsf(c0.z) * ex + fabsf(c1.z) * ey) + fabsf(c2.z) * ez) + fabsf(c3.z);
+    bool outside = false;
+#pragma unroll
+    for (int p = 0; p < 5; p++) {
+        const float nx = view_dev ? view_dev->frustum[p][0] : pv.frustum[p][0];
+        const float ny = view_dev ? view_dev->frustum[p][1] : pv.frustum[p][1];
+        const float nz = view_dev ? view_dev->frustum[p][2] : pv.frustum[p][2];
+        const float d = view_dev ? view_dev->frustum[p][3] : pv.frustum[p][3];
+        const float nlen = fmaxf(sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
+        const float reach = nlen * F * R;
+        const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
+        const float e = (((nx * wx + ny * wy) + nz * wz) + d) + reach + A * 1.52587890625e-5f;  // 2^-16
+        outside |= e < 0.0f;
+    }
+    return outside;
+}
+
+// Two output forms.  skip != nullptr (the multi-view pass): one byte per group (ranged scenes) or per
+// instance (uniform scenes), 1 = certainly outside.  Otherwise a WORK LIST for the single-view mask pass
+// (layout above; work[0] is zero on entry).  Each workgroup reserves room for the survivors among its 512
+// instances with one atomic, so the list is ordered inside a workgroup's share and in arrival order
+// between workgroups; the mask pass does not depend on the order.  It then never starts a wave for a group
+// that is not in the list: the ballots of those groups are zeroed beforehand.
+__global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *__restrict__ transforms,
+                                                                  const float4 *__restrict__ spheres, uint32_t per_instance_sphere,
+                                                                  const uint2 *__restrict__ ranges,
+                                                                  const uint32_t *__restrict__ group_base, uint32_t n_instances,
+                                                                  uint32_t groups_per_instance, uint64_t units, PreView pv, const ViewConst *__restrict__ view_dev,
+                                                                  uint8_t *__restrict__ skip, uint32_t *__restrict__ work,
+                                                                  uint64_t *__restrict__ zero_mask) {
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_base;
+    const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
+    bool outside[kPreItems];
+#pragma unroll
+    for (int q = 0; q < kPreItems; q++)
+        outside[q] = i0 + q < n_instances ? instance_outside(transforms, spheres, per_instance_sphere, i0 + q, pv, view_dev) : true;
+    if (skip) {  // uniform over the launch
+#pragma unroll
+        for (int q = 0; q < kPreItems; q++) {
+            const uint32_t i = i0 + q;
+            if (i >= n_instances) break;
+            const uint8_t flag = outside[q] ? 1 : 0;
+            if (group_base) {
+                const uint32_t b = group_base[i], e = group_base[i + 1];
+                for (uint32_t g = b; g < e; g++) skip[g] = flag;
+            } else {
+                skip[i] = flag;
+            }
+        }
+        return;
+    }
+    uint32_t first[kPreItems], n[kPreItems], mine = 0;
+#pragma unroll
+    for (int q = 0; q < kPreItems; q++) {
+        first[q] = i0 + q;
+        n[q] = outside[q] ? 0u : 1u;
+        if (group_base && i0 + q < n_instances) {
+            first[q] = group_base[i0 + q];
+            const uint32_t groups = group_base[i0 + q + 1] - first[q];
+            if (n[q]) n[q] = groups;
+            else if (zero_mask)  // a dropped instance: its groups' ballots are all zero
+                for (uint32_t j = 0; j < groups; j++) zero_mask[first[q] + j] = 0ull;
+        } else if (zero_mask && !n[q] && i0 + q < n_instances) {
+            for (uint32_t j = 0; j < groups_per_instance; j++) zero_mask[(size_t)(i0 + q) * groups_per_instance + j] = 0ull;
+        }
+        mine += n[q];
+    }
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(mine, s_wave, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&work[0], total) : 0u;
+    __syncthreads();
+    uint32_t pos = s_base + excl;
+    uint32_t *out_g = work + kWorkHeader;
+    uint4 *out_rec = reinterpret_cast<uint4 *>(work + work_rec_offset_words(units));
+#pragma unroll
+    for (int q = 0; q < kPreItems; q++) {
+        if (!n[q]) continue;
+        if (group_base) {
+            const uint2 r = ranges[i0 + q];
+            for (uint32_t j = 0; j < n[q]; j++) {
+                const uint32_t left = r.y - j * 64u;
+                out_g[pos + j] = first[q] + j;
+                out_rec[pos + j] = make_uint4(i0 + q, r.x + j * 64u, left < 64u ? left : 64u, j);
+            }
+        } else {
+            out_g[pos] = first[q];
+        }
+        pos += n[q];
+    }
+}
+
+// Number of set bytes (on request only: the statistics of the last pre-cull).
+__global__ __launch_bounds__(kBlock) void count_bytes_kernel(const uint8_t *__restrict__ bytes, uint64_t n,
+                                                             unsigned long long *__restrict__ out) {
+    __shared__ uint32_t s_sum[kWaves];
+    uint32_t x = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock) x += bytes[j] ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])));
+}
+
 // ------------------------------------------------------------------------------------------------
 // ordered, pass 1: visibility ballots.  Small workgroups: each of the 4 waves takes NG consecutive
 // groups.  The workgroup first stages the 4*NG group records in LDS, then requests every group's
@@ -352,14 +594,15 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v_arg,
     uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous,
-    const ViewConst *__restrict__ view_dev) {
+    const ViewConst *__restrict__ view_dev, const uint32_t *__restrict__ work, uint32_t *__restrict__ kept_report) {
     const ViewConst &v = VP ? *view_dev : v_arg;
     const uint32_t tests = VP ? v.tests : TESTS;
     constexpr uint32_t kGroups = kWaves * NG;  // groups per workgroup
     __shared__ uint4 s_rec[kGroups];
     __shared__ float4 s_x[kGroups][4];
     __shared__ float s_scale[kGroups];
-    __shared__ uint32_t s_count[kWaves];
+    __shared__ uint32_t s_g[kGroups];    // index of each slot's group in the scene (its ballot word, its tile)
+    __shared__ uint32_t s_pop[kGroups];  // visible pairs of each slot's group
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // Workgroups are dealt to the 8 XCDs round-robin by id.  xcd_contiguous != 0 renumbers them so that
@@ -367,12 +610,43 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     uint32_t block = blockIdx.x;
     if (xcd_contiguous) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint32_t block_g0 = block * kGroups;
-    if (block_g0 >= n_groups) return;  // padding workgroups of a rounded-up grid
+    // With a work list (instance_precull_kernel) the pass runs over the list's groups only: the grid is
+    // sized for the whole scene and the workgroups beyond the list's end leave at once.
+    // The list's length is device data.  So that no workgroup waits for it before it can ask for its records,
+    // the slots read the list speculatively - at positions clamped to the list's capacity, which may hold
+    // entries of an earlier cull - and what lies past the end is thrown away once the length has arrived,
+    // before anything is addressed with it.
+    if (block_g0 >= n_groups) return;  // the padding workgroups of a rounded-up grid
+    uint32_t g = 0;
+    GroupInfo gi = {0u, 0u, 0u, 0u};
+    const uint32_t w = block_g0 + threadIdx.x;
     if (threadIdx.x < kGroups) {
-        const uint32_t g = block_g0 + threadIdx.x;
-        GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, v.uniform_count);
-        if (g >= n_groups) gi.count = 0;  // out-of-range groups re-read a valid element and report nothing
+        const uint32_t wc = w < n_groups ? w : n_groups - 1u;  // slots past the end re-read a valid element and report nothing
+        g = wc;
+        if (work && group_rec) {  // the list carries the record beside the group's index: two independent loads
+            g = work[kWorkHeader + wc];
+            const uint4 r = reinterpret_cast<const uint4 *>(work + work_rec_offset_words(n_groups))[wc];
+            gi.inst = r.x; gi.first_meshlet = r.y; gi.count = r.z; gi.local_group = r.w;
+        } else {
+            if (work) {
+                const uint32_t item = wc / groups_per_instance;
+                g = work[kWorkHeader + item] * groups_per_instance + (wc - item * groups_per_instance);
+            }
+            gi = group_lookup(g, group_rec, groups_per_instance, v.uniform_count);
+        }
+    }
+    uint32_t n_run = n_groups;
+    if (work) n_run = group_rec ? work[0] : work[0] * groups_per_instance;
+    // how much the pre-cull kept, left where the host can look at it later without waiting (host-mapped memory)
+    if (work && kept_report && blockIdx.x == 0 && threadIdx.x == 0) *kept_report = work[0];
+    if (block_g0 >= n_run) return;  // workgroups beyond the list's end
+    if (threadIdx.x < kGroups) {
+        if (w >= n_run) {  // nothing of a slot past the end is used: it re-reads element 0 and reports nothing
+            g = 0u;
+            gi = GroupInfo{0u, 0u, 0u, 0u};
+        }
         s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
+        s_g[threadIdx.x] = g;
     }
     __syncthreads();
     if (threadIdx.x < kGroups * 4) {
@@ -390,7 +664,6 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
         c[k] = load_bounds<NT>(centre_radius + id);
     }
     __syncthreads();
-    uint32_t count = 0;
     auto load_xform_lds = [&](uint32_t slot) {
         Xform m;
         m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
@@ -399,8 +672,10 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     auto publish = [&](uint32_t slot, bool vis) {
         const uint32_t n_valid = s_rec[slot].z;
         const uint64_t ballot = __ballot(vis && (lane < n_valid));
-        if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
-        count += (uint32_t)__popcll(ballot);
+        if (lane == 0) {
+            if (n_valid) mask[s_g[slot]] = ballot;
+            s_pop[slot] = (uint32_t)__popcll(ballot);
+        }
     };
     if constexpr (NG % 2 == 0 && NT) {
 #pragma unroll
@@ -419,11 +694,16 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
             publish(slot, pair_visible_impl<NT>(tests, v, load_xform_lds(slot), s_scale[slot], a[k], c[k]));
         }
     }
-    if (lane == 0) s_count[wave] = count;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t sum = (s_count[0] + s_count[1]) + (s_count[2] + s_count[3]);
-        if (sum) atomicAdd(&tile_counts[block_g0 / kTileGroups], sum);
+    // One atomic per run of slots that share a 256-group tile: without a work list that is one per
+    // workgroup (16 consecutive groups never straddle a tile), with one a handful at most.
+    if (threadIdx.x < kGroups) {
+        const uint32_t k = threadIdx.x, tile = s_g[k] / kTileGroups;
+        if (k == 0 || s_g[k - 1] / kTileGroups != tile) {
+            uint32_t sum = 0;
+            for (uint32_t j = k; j < kGroups && s_g[j] / kTileGroups == tile; j++) sum += s_pop[j];
+            if (sum) atomicAdd(&tile_counts[tile], sum);
+        }
     }
 }
 
@@ -437,6 +717,7 @@ struct ViewSet {
     ViewConst v[MCULL_MAX_VIEWS];
     uint64_t *mask[MCULL_MAX_VIEWS];
     uint32_t *tile_counts[MCULL_MAX_VIEWS];
+    const uint8_t *skip[MCULL_MAX_VIEWS];  // the view's instance pre-cull bytes, or nullptr
     uint32_t n;
 };
 
@@ -453,6 +734,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     __shared__ float4 s_x[kGroups][4];
     __shared__ float s_scale[kGroups];
     __shared__ uint32_t s_count[MCULL_MAX_VIEWS][kWaves];
+    __shared__ uint32_t s_skip[kGroups];  // bit i: view i's pre-cull marked the group's instance
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t block_g0 = blockIdx.x * kGroups;
@@ -460,6 +742,11 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         const uint32_t g = block_g0 + threadIdx.x;
         GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, vs.v[0].uniform_count);
         if (g >= n_groups) gi.count = 0;
+        uint32_t bits = 0;
+        if (g < n_groups)
+            for (uint32_t i = 0; i < vs.n; i++)
+                if (vs.skip[i] && vs.skip[i][group_rec ? g : gi.inst]) bits |= 1u << i;
+        s_skip[threadIdx.x] = bits;
         s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
     }
     __syncthreads();
@@ -469,11 +756,15 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         if (j == 0) s_scale[k] = xf_scale[s_rec[k].x];
     }
     float4 a[NG], c[NG];
+    uint32_t skip_bits[NG];
+    const uint32_t all_views = (1u << vs.n) - 1u;
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const uint4 r = s_rec[wave * NG + k];
+        skip_bits[k] = __builtin_amdgcn_readfirstlane(s_skip[wave * NG + k]);
         const uint32_t last = r.z ? r.z - 1u : 0u;
-        const uint32_t id = r.y + (lane < last ? lane : last);
+        // a group no view needs moves no bounds: its lanes re-read element 0 (see cull_mask_kernel)
+        const uint32_t id = skip_bits[k] == all_views ? 0u : r.y + (lane < last ? lane : last);
         a[k] = load_bounds<NT>(cone_axis_w + id);
         c[k] = load_bounds<NT>(centre_radius + id);
     }
@@ -513,10 +804,13 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
 #pragma unroll
             for (int k = 0; k < NG; k += 2) {
                 const uint32_t slot = wave * NG + k;
-                bool vis0, vis1;
+                bool vis0 = false, vis1 = false;
                 const uint32_t n0 = s_rec[slot].z, n1 = s_rec[slot + 1].z;
-                tests2<NT, true>(v.tests, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], lane < n0, lane < n1, vis0, vis1);
-                const uint64_t b0 = __ballot(vis0 && lane < n0), b1 = __ballot(vis1 && lane < n1);
+                const bool live0 = !((skip_bits[k] >> i) & 1u), live1 = !((skip_bits[k + 1] >> i) & 1u);
+                if (live0 || live1)
+                    tests2<NT, true>(v.tests, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], live0 && lane < n0,
+                                     live1 && lane < n1, vis0, vis1);
+                const uint64_t b0 = __ballot(vis0 && live0 && lane < n0), b1 = __ballot(vis1 && live1 && lane < n1);
                 if (lane == 0 && n0) mask[block_g0 + slot] = b0;
                 if (lane == 0 && n1) mask[block_g0 + slot + 1] = b1;
                 count += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
@@ -526,7 +820,8 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
             for (int k = 0; k < NG; k++) {
                 const uint32_t slot = wave * NG + k;
                 const uint32_t n_valid = s_rec[slot].z;
-                const bool vis = pair_visible_prepared<NT>(v.tests, v, m[k], wc[k], wa[k]) && (lane < n_valid);
+                bool vis = false;
+                if (!((skip_bits[k] >> i) & 1u)) vis = pair_visible_prepared<NT>(v.tests, v, m[k], wc[k], wa[k]) && (lane < n_valid);
                 const uint64_t ballot = __ballot(vis);
                 if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
                 count += (uint32_t)__popcll(ballot);
@@ -540,30 +835,6 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         const uint32_t sum = (s_count[i][0] + s_count[i][1]) + (s_count[i][2] + s_count[i][3]);
         if (sum) atomicAdd(&vs.tile_counts[i][block_g0 / kTileGroups], sum);
     }
-}
-
-// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
-// prefix and writes the workgroup total to *total_out (uniform).
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s_wave /*[kWaves]*/, uint32_t *total_out) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += up;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; w++) {
-        const uint32_t t = s_wave[w];
-        if ((uint32_t)w < wave) wave_base += t;
-        total += t;
-    }
-    *total_out = total;
-    __syncthreads();  // s_wave may be reused by the caller's next scan
-    return wave_base + incl - x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,39 +1171,40 @@ bool needs_tile_offsets(uint64_t n_groups) { return tile_count_for(n_groups) > k
 
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                               const ViewConst *view_dev, hipStream_t st) {
+                               const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report, hipStream_t st) {
     const uint32_t per_block = kWaves * NG;
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
     if (view_dev) {
         hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                            s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                           tile_counts, 0u, view_dev);
+                           tile_counts, 0u, view_dev, work, kept_report);
         return;
     }
     MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
                                                      s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                      s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
-                                                     (const ViewConst *)nullptr));
+                                                     (const ViewConst *)nullptr, work, kept_report));
 }
 
 // view_dev != nullptr: the kernels take the view constants (and the tests) from that device record
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                            bool streaming, hipStream_t st, const ViewConst *view_dev) {
+                            bool streaming, hipStream_t st, const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report) {
     // groups per wave: more requests in flight per wave for big scenes, enough workgroups to fill
     // 256 CUs for small ones
     if (streaming) {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, st);
-        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, work, kept_report, st);
+        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, work, kept_report, st);
     } else {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, st);
-        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, st);
-        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, work, kept_report, st);
+        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, work, kept_report, st);
+        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, work, kept_report, st);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
-                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev) {
+                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev,
+                                  const uint8_t *const *skips) {
     ViewSet vs;
     std::memset(&vs, 0, sizeof vs);
     vs.n = n_views;
@@ -940,6 +1212,7 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
         vs.v[i] = *views[i];
         vs.mask[i] = masks[i];
         vs.tile_counts[i] = tile_counts[i];
+        vs.skip[i] = skips ? skips[i] : nullptr;
     }
     // two groups per wave: each group is evaluated n_views times, which hides the load latency that
     // the single-view kernel hides with four groups in flight
@@ -1015,6 +1288,41 @@ hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visib
                                                          s.groups_per_instance, (uint32_t)s.n_groups, v, list, capacity,
                                                          inst_count, (unsigned long long *)total, mask));
     }
+    return hipGetLastError();
+}
+
+// spheres[i] for ranges[i] (n_ranges of them), or spheres[0] for [0, uniform_count) when ranges == nullptr
+hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
+                                float4 *spheres, hipStream_t st) {
+    if (n_ranges == 0) return hipSuccess;
+    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, spheres);
+    return hipGetLastError();
+}
+
+size_t work_list_bytes(uint64_t units, bool ranged) { return work_rec_offset_words(units) * 4 + (ranged ? units * 16 : 0); }
+
+// Exactly one of skip / work: skip = one byte per group (group_base != nullptr) or per instance; work = a work
+// list of work_list_bytes(groups or instances) whose first word the caller has zeroed; zero_mask (list form,
+// optional): the ballot words, of which the pre-pass zeroes those of the groups it drops.
+hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
+                                   const ViewConst &v, const ViewConst *view_dev, uint8_t *skip, uint32_t *work, uint64_t *zero_mask,
+                                   hipStream_t st) {
+    if (s.n_instances == 0) return hipSuccess;
+    PreView pv;
+    std::memcpy(pv.frustum, v.frustum, sizeof pv.frustum);
+    const uint32_t per_block = kBlock * kPreItems;
+    hipLaunchKernelGGL(instance_precull_kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kBlock), 0, st, s.transforms,
+                       spheres, per_instance_sphere ? 1u : 0u, s.ranges, group_base, s.n_instances, s.groups_per_instance,
+                       group_base ? s.n_groups : (uint64_t)s.n_instances, pv, view_dev, skip, work, zero_mask);
+    return hipGetLastError();
+}
+
+// *out (zeroed by the caller) += number of non-zero bytes
+hipError_t launch_count_bytes(const uint8_t *bytes, uint64_t n, uint64_t *out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n + kBlock * 16 - 1) / (kBlock * 16);
+    hipLaunchKernelGGL(count_bytes_kernel, dim3((uint32_t)(want < 1024 ? want : 1024)), dim3(kBlock), 0, st, bytes, n,
+                       (unsigned long long *)out);
     return hipGetLastError();
 }
 

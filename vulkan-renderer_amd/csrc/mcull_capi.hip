@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -93,6 +94,19 @@ struct mcull_ctx {
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
     bool geometry_checked = false;  // the uploaded meshlets index only inside the uploaded geometry (host check done)
     uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
+    // instance pre-cull: one enclosing sphere per instance range (ranged scenes) or one for [0, meshletCount);
+    // computed on the first cull after the bounds or the ranges changed
+    DevBuf range_spheres;
+    bool spheres_valid = false, spheres_ranged = false;
+    uint32_t spheres_uniform_count = 0;
+    // A pre-cull that removes next to nothing costs its own pass and a slower mask pass (100 M pairs, all in
+    // view: 0.77 against 0.69 ms).  Each single-view cull that runs it leaves the number of units it kept in
+    // host-mapped memory (kept_host[slot], read later without waiting); when that was more than 90 % of the
+    // units, the following kPrecullCooldown culls of the slot go without, then it is tried again.
+    // MCULL_PRECULL_ADAPTIVE=0 switches the back-off off (tests that look at the pre-cull's statistics).
+    volatile uint32_t *kept_host = nullptr;  // MCULL_MAX_VIEWS words, hipHostMalloc (mapped)
+    uint32_t *kept_dev = nullptr;            // the same memory as the device sees it
+    bool precull_adaptive = true;
 
     // Hi-Z
     HizSlot hiz[MCULL_MAX_VIEWS];
@@ -102,6 +116,8 @@ struct mcull_ctx {
     DevBuf view_dev;  // MCULL_MAX_VIEWS + 1 device-resident ViewConst records (the *_device_globals calls; the last one is the rasteriser's)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
+    uint64_t precull_min_groups = 2048;  // scenes below this many 64-meshlet groups are launch-bound: the instance pre-cull's extra
+                                         // launch does not pay (MCULL_PRECULL_MIN_GROUPS overrides it, for tests)
     bool force_streaming = false;  // MCULL_FORCE_STREAMING=1: the kernels for bounds larger than the caches, whatever the size (tests)
 
     // cull scratch + outputs, one set per view slot: mcull_cull uses slot 0, mcull_cull_views slot i
@@ -117,13 +133,21 @@ struct mcull_ctx {
         void *commands = nullptr;
         bool have_mask = false;
         uint64_t n_pairs = 0;
+        // the instance pre-cull of this cull: its work list (single view) or its bytes (one of several views),
+        // over `precull_units` groups (ranged scenes) or instances; both nullptr when it did not run
+        const uint32_t *work = nullptr;
+        const uint8_t *skip = nullptr;
+        uint64_t precull_units = 0;
     };
     struct ViewOut {
-        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands;
+        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, skip, work;
         uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
         bool counters_clean = false;   // tile counters are all zero (the mask pass adds into them, the command pass re-zeroes)
         uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
         Last last;                      // description of the last cull (for rebase / downloads / payloads)
+        bool probe_pending = false;     // a pre-cull ran and its kept count has not been looked at yet
+        uint64_t probe_units = 0;
+        uint32_t precull_cooldown = 0;  // culls still to go without the pre-cull
     } out[MCULL_MAX_VIEWS];
     uint32_t cur = 0;
 };
@@ -311,6 +335,20 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
     const char *fs = std::getenv("MCULL_FORCE_STREAMING");
     c->force_streaming = fs && fs[0] == '1';
+    if (const char *pm = std::getenv("MCULL_PRECULL_MIN_GROUPS")) c->precull_min_groups = std::strtoull(pm, nullptr, 10);
+    if (const char *pa = std::getenv("MCULL_PRECULL_ADAPTIVE")) c->precull_adaptive = pa[0] != '0';
+    void *host_words = nullptr, *dev_words = nullptr;
+    if (hipHostMalloc(&host_words, MCULL_MAX_VIEWS * 4, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dev_words, host_words, 0) != hipSuccess) {
+        if (host_words) (void)hipHostFree(host_words);
+        (void)hipEventDestroy(c->ev0);
+        (void)hipEventDestroy(c->ev1);
+        delete c;
+        return MCULL_E_HIP;
+    }
+    c->kept_host = static_cast<volatile uint32_t *>(host_words);
+    c->kept_dev = static_cast<uint32_t *>(dev_words);
+    for (int i = 0; i < MCULL_MAX_VIEWS; i++) c->kept_host[i] = 0xffffffffu;
     c->hiz_mode = (single && single[0] == '1') ? 2 : (tiles && tiles[0] == '1') ? 1 : (streamed && streamed[0] == '1') ? 3 : 0;
     *out = c;
     return MCULL_OK;
@@ -321,14 +359,16 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch};
+                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch,
+                      &c->range_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
-        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands})
+        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.skip, &o.work})
             release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->kept_host) (void)hipHostFree(const_cast<uint32_t *>(c->kept_host));
     delete c;
     return MCULL_OK;
 }
@@ -361,6 +401,7 @@ int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t 
     c->have_aos = true;
     c->geometry_checked = false;
     c->have_bounds = true;
+    c->spheres_valid = false;  // the pre-cull's range spheres derive from the bounds
     invalidate_results(c);
     return MCULL_OK;
 }
@@ -390,6 +431,7 @@ int mcull_upload_bounds_soa(mcull_ctx *c, const float *cone_axis_w, const float 
     c->n_meshlets = count;
     c->have_aos = false;
     c->have_bounds = true;
+    c->spheres_valid = false;
     invalidate_results(c);
     return MCULL_OK;
 }
@@ -457,6 +499,7 @@ int mcull_compute_bounds(mcull_ctx *c) {
         c->timed = true;
     }
     c->have_bounds = true;
+    c->spheres_valid = false;
     return MCULL_OK;
 }
 
@@ -492,6 +535,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
     if (!c) return MCULL_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     invalidate_results(c);
+    c->spheres_valid = false;
     if (!meshlet_offset || !meshlet_count) {
         c->have_ranges = false;
         return MCULL_OK;
@@ -614,6 +658,8 @@ namespace {
 
 // Everything mcull_cull decides before it launches: validated parameters, the scene and view
 // constants, and the output buffers of one view slot (allocated here).
+constexpr uint32_t kPrecullCooldown = 15;  // culls without the pre-cull after one that kept more than 90 % of the units
+
 struct CullPlan {
     mcull_cull_params p;
     mcull::SceneDev s;
@@ -627,6 +673,9 @@ struct CullPlan {
     mcull::CmdLayout lay;
     bool want_mask, two_level, streaming;
     uint32_t n_tiles;
+    uint8_t *skip;              // instance pre-cull of this cull: bytes (multi-view pass) or work list (single view),
+    uint32_t *work;             // both nullptr when it does not run
+    uint64_t precull_units;     // groups (ranged scenes) or instances it decides about
 };
 
 // The half of the plan that allocates nothing: validated parameters, scene and view constants, sizes.
@@ -695,6 +744,9 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
         v.pyramid = (const float *)hs.pyramid.p;
     }
     plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
+    plan->skip = nullptr;
+    plan->work = nullptr;
+    plan->precull_units = 0;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
     plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
     plan->two_level = mcull::needs_tile_offsets(s.n_groups);
@@ -705,7 +757,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
 
 // The other half: the output and scratch buffers of one view slot (allocated or grown here).
 int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, const mcull_cull_params *params, mcull_ctx::ViewOut &o,
-              CullPlan *plan) {
+              CullPlan *plan, bool multi_view = false) {
     if (int rc0 = plan_inputs(c, g, meshlet_count, params, plan)) return rc0;
     mcull_cull_params &p = plan->p;
     mcull::SceneDev &s = plan->s;
@@ -735,6 +787,47 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
+        bool precull = (p.tests & MCULL_TEST_FRUSTUM) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) && s.n_groups >= c->precull_min_groups;
+        if (precull && !multi_view && c->precull_adaptive) {
+            const size_t slot = (size_t)(&o - c->out);
+            if (o.probe_pending) {
+                const uint32_t kept = c->kept_host[slot];
+                if (kept != 0xffffffffu) {  // the cull that ran it has finished
+                    o.probe_pending = false;
+                    if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown = kPrecullCooldown;
+                }
+            }
+            if (o.precull_cooldown) {
+                o.precull_cooldown--;
+                precull = false;
+            }
+        }
+        if (precull) {
+            // instance pre-cull: its range spheres (recomputed after the bounds or ranges changed) and its output bytes
+            const bool ranged = c->have_ranges;
+            if (!c->spheres_valid || c->spheres_ranged != ranged || (!ranged && c->spheres_uniform_count != plan->uniform_count)) {
+                const uint32_t n_ranges = ranged ? (uint32_t)c->n_instances : 1u;
+                if ((rc = ensure(c, c->range_spheres, (size_t)n_ranges * 16))) return rc;
+                HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, plan->uniform_count,
+                                                      (float4 *)c->range_spheres.p, c->stream));
+                c->spheres_valid = true;
+                c->spheres_ranged = ranged;
+                c->spheres_uniform_count = plan->uniform_count;
+            }
+            plan->precull_units = ranged ? s.n_groups : c->n_instances;
+            if (multi_view) {
+                if ((rc = ensure(c, o.skip, plan->precull_units))) return rc;
+                plan->skip = (uint8_t *)o.skip.p;
+            } else {
+                if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
+                plan->work = (uint32_t *)o.work.p;
+                if (c->precull_adaptive && !o.probe_pending) {
+                    c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
+                    o.probe_pending = true;
+                    o.probe_units = plan->precull_units;
+                }
+            }
+        }
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
         if ((rc = ensure(c, o.tile_counts, (size_t)plan->n_tiles * 4))) return rc;
         if (plan->two_level && (rc = ensure(c, o.tile_offsets, (size_t)plan->n_tiles * 8))) return rc;
@@ -769,6 +862,9 @@ void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *r
     o.last.commands = pl.commands;
     o.last.have_mask = pl.want_mask;  // a scene without any group has a mask of zero words
     o.last.n_pairs = pl.n_pairs;
+    o.last.skip = pl.skip;
+    o.last.work = pl.work;
+    o.last.precull_units = pl.precull_units;
     if (result) {
         result->list = pl.list;
         result->commands = pl.commands;
@@ -812,8 +908,18 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
                                               (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
+        if (pl.work) {
+            // the mask pass will cover the work list's groups only: every other ballot is zero from here
+            HIPCHK(c, hipMemsetAsync(pl.work, 0, 4, c->stream));
+            // few groups per instance: the pre-pass zeroes the dropped groups' ballots itself; many: one memset
+            const bool inline_zero = pl.s.n_groups <= 8ull * pl.s.n_instances;
+            if (!inline_zero) HIPCHK(c, hipMemsetAsync(o.mask.p, 0, pl.s.n_groups * 8, c->stream));
+            HIPCHK(c, mcull::launch_instance_precull(pl.s, (const float4 *)c->range_spheres.p, c->have_ranges,
+                                                     c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl.v, view_dev,
+                                                     nullptr, pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, c->stream));
+        }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
-                                          c->stream, view_dev));
+                                          c->stream, view_dev, pl.work, c->precull_adaptive ? c->kept_dev : nullptr));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
@@ -912,7 +1018,7 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
     HIPCHK(c, hipSetDevice(c->device));
     CullPlan pl[MCULL_MAX_VIEWS];
     for (uint32_t i = 0; i < n_views; i++) {
-        if (int rc = plan_cull(c, globals ? &globals[i] : nullptr, meshlet_count, params ? &params[i] : nullptr, c->out[i], &pl[i]))
+        if (int rc = plan_cull(c, globals ? &globals[i] : nullptr, meshlet_count, params ? &params[i] : nullptr, c->out[i], &pl[i], true))
             return rc;
         if (pl[i].p.compaction != MCULL_COMPACT_ORDERED)
             return fail(c, MCULL_E_INVALID, "mcull_cull_views supports ordered compaction only (view %u)", i);
@@ -946,12 +1052,18 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
         const mcull::ViewConst *vc[MCULL_MAX_VIEWS];
         uint64_t *masks[MCULL_MAX_VIEWS];
         uint32_t *counts[MCULL_MAX_VIEWS];
+        const uint8_t *skips[MCULL_MAX_VIEWS];
         for (uint32_t i = 0; i < n_views; i++) {
             vc[i] = &pl[i].v;
             masks[i] = (uint64_t *)c->out[i].mask.p;
             counts[i] = (uint32_t *)c->out[i].tile_counts.p;
+            skips[i] = pl[i].skip;
+            if (pl[i].skip)
+                HIPCHK(c, mcull::launch_instance_precull(pl[i].s, (const float4 *)c->range_spheres.p, c->have_ranges,
+                                                         c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl[i].v,
+                                                         view_dev ? view_dev + i : nullptr, pl[i].skip, nullptr, nullptr, c->stream));
         }
-        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev));
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev, skips));
         for (uint32_t i = 0; i < n_views; i++)
             if (int rc = launch_ordered_tail(c, c->out[i], pl[i])) return rc;
     }
@@ -1084,6 +1196,32 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
         HIPCHK(c, hipMemcpyAsync(out, o.mask.p, words * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return MCULL_OK;
+}
+
+int mcull_precull_stats(mcull_ctx *c, uint64_t *instances_or_groups_marked, uint64_t *bytes_tested, int *per_group) {
+    if (!c) return MCULL_E_INVALID;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    if (instances_or_groups_marked) *instances_or_groups_marked = 0;
+    if (bytes_tested) *bytes_tested = o.last.precull_units;
+    if (per_group) *per_group = o.last.scene.group_rec != nullptr;
+    if (!o.last.skip && !o.last.work) return MCULL_OK;  // the pre-cull did not run for this cull
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t n = 0;
+    if (o.last.work) {  // the list's length is the number of survivors
+        uint32_t kept = 0;
+        HIPCHK(c, hipMemcpyAsync(&kept, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        n = o.last.precull_units - kept;
+    } else {
+        uint64_t *slot = (uint64_t *)o.total.p + 8;  // spare words of the context-owned count buffer
+        HIPCHK(c, hipMemsetAsync(slot, 0, 8, c->stream));
+        HIPCHK(c, mcull::launch_count_bytes(o.last.skip, o.last.precull_units, slot, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&n, slot, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (instances_or_groups_marked) *instances_or_groups_marked = n;
     return MCULL_OK;
 }
 
