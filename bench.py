@@ -426,7 +426,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     cmds = [x[:n_inst] for x in cmds_packed]
     total = [x[n_rows:].view(torch.int64) for x in cmds_packed]
     # multi-view: the last view writes the buffers the collectives read; the others stay context-owned
-    view_params = [[dict(tests=tests, hiz_view=v, precull=not args.no_precull) for v in range(n_views)] for _ in range(2)]
+    view_params = [[dict(tests=tests, hiz_view=v, precull=not args.no_precull, exact=args.exact) for v in range(n_views)] for _ in range(2)]
     for bb in range(2):
         view_params[bb][-1].update(list_ptr=lst.data_ptr(), list_capacity=cap, commands_ptr=cmds[bb].data_ptr(),
                                    total_ptr=total[bb].data_ptr())
@@ -461,11 +461,11 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                         ms += ctx.last_kernel_ms()
                 if args.ctx_outputs:
                     ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, total_ptr=total[b].data_ptr(),
-                             precull=not args.no_precull)
+                             precull=not args.no_precull, exact=args.exact)
                 else:
                     ctx.cull(views[v], tests=tests, hiz_view=v, compaction=args.compaction, list_ptr=lst.data_ptr(),
                              list_capacity=cap, commands_ptr=cmds[b].data_ptr(), total_ptr=total[b].data_ptr(),
-                             precull=not args.no_precull)
+                             precull=not args.no_precull, exact=args.exact)
                 if record:
                     ms += ctx.last_kernel_ms()
         if multi:
@@ -1025,6 +1025,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="config1: also replay the frame as one captured HIP graph")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-precull", action="store_true", help="cull workloads: switch the instance-level pre-cull off")
+    ap.add_argument("--exact", action="store_true",
+                    help="cull workloads: every pair through the IEEE expressions instead of the guarded fast forms (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bounds-copies", type=int, default=64, help="bounds workload: copies of the kitten fixture")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")

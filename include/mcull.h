@@ -136,16 +136,28 @@ typedef struct mcull_task_payload {
 #define MCULL_CMD_EXT_GROUPS 1
 
 /* mcull_cull_params.flags.
- * Ordered culls that run the frustum test first test ONE enclosing sphere per instance (of the
- * instance's whole meshlet range, computed once after an upload) against the five planes, with a margin
+ * Ordered single-view culls (mcull_cull, mcull_cull_device_globals) that run the frustum test first test ONE
+ * enclosing sphere per instance (of the instance's whole meshlet range, computed once after an upload)
+ * against the five planes, with a margin
  * that covers the rounding of the per-meshlet expression; the groups of an instance that is certainly
  * outside get zero ballots without a meshlet being loaded or tested.  Results are identical with and
  * without it.  The reference has no such level: it launches every task group of every draw
  * (Engine.cpp:1475-1483, shader.task:79-102).  MCULL_CULL_NO_INSTANCE_PRECULL switches it off
- * (measurements, parity tests).  Bounds that were adopted in place (mcull_upload_bounds_soa with adopt)
+ * (measurements, parity tests); the library also drops it by itself for a while after a cull in which it
+ * removed less than a tenth of the scene.  mcull_cull_views and mcull_cull_static have no such level.
+ * Bounds that were adopted in place (mcull_upload_bounds_soa with adopt)
  * must be announced again with that call after their contents change: the range spheres are derived
  * from them. */
 #define MCULL_CULL_NO_INSTANCE_PRECULL 1u
+/* The cone and occlusion tests are evaluated in a guarded-exact form: first with the hardware's approximate
+ * reciprocal / reciprocal square root and an error bound, and with the correctly rounded IEEE expressions
+ * (the ones the oracle evaluates; GLSL itself leaves the precision of /, sqrt, normalize open,
+ * shader.task:39, :62-63) only for the pairs whose decision the bound could change.  Every decision, and so
+ * every output, is bit-identical to the all-IEEE evaluation.  MCULL_CULL_EXACT_ARITHMETIC sends every pair
+ * through the IEEE expressions (measurements, parity tests); MCULL_CULL_COUNT_SLOW_PAIRS counts the pairs
+ * that had to (mcull_slow_path_pairs; costs one atomic per affected wave). */
+#define MCULL_CULL_EXACT_ARITHMETIC 2u
+#define MCULL_CULL_COUNT_SLOW_PAIRS 4u
 
 /* VkDrawMeshTasksIndirectCommandEXT as written for MCULL_CMD_EXT_GROUPS. 12 bytes. */
 typedef struct mcull_mesh_tasks_cmd_ext {
@@ -333,11 +345,15 @@ int mcull_download_list(mcull_ctx *ctx, mcull_visible *out, uint64_t capacity, u
 int mcull_download_commands(mcull_ctx *ctx, void *out, uint64_t bytes);
 int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
 
+/* Pairs of the last cull (run with MCULL_CULL_COUNT_SLOW_PAIRS) that left the fast predicate forms for the
+ * IEEE expressions, counted once per test that sent them there.  Synchronous.  No reference counterpart. */
+int mcull_slow_path_pairs(mcull_ctx *ctx, uint64_t *pairs);
+
 /* What the instance pre-cull of the last cull removed (synchronous; one small counting kernel, run on
  * request only).  *marked = instances marked as certainly outside the frustum (scenes without instance
  * ranges) or 64-meshlet groups of such instances (scenes with ranges: *per_group != 0); *tested = how many
- * instances / groups there were.  0 / 0 when the pre-cull did not run (frustum test off, switched off,
- * scene below 2048 groups, unordered compaction).  No reference counterpart. */
+ * instances / groups there were.  0 / 0 when the pre-cull did not run (frustum test off, switched off or
+ * backed off, scene below 2048 groups, unordered compaction, one of several views).  No reference counterpart. */
 int mcull_precull_stats(mcull_ctx *ctx, uint64_t *marked, uint64_t *tested, int *per_group);
 
 /* Device timestamps around the kernels of each mcull_cull / mcull_hiz_build /

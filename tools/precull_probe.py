@@ -12,11 +12,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+os.environ.setdefault("MCULL_PRECULL_ADAPTIVE", "0")
 mc = importlib.import_module("vulkan-renderer_amd")
 host = importlib.import_module("vulkan-renderer_amd.host")
 dev = torch.device("cuda", 0)
 n_inst, per = 781250, 128
 cone, sphere, xf = bench.make_scene_range(dev, 0, n_inst, per, seed=42)
+if "--sorted" in sys.argv:
+    # the same instances, those outside the bench camera's frustum first: the pre-cull then drops one contiguous
+    # third of the scene instead of scattered instances
+    g0 = host.create_globals(fov_deg=45.0, width=3840, height=2160, flip_y=True, eye=(51.0, 54.4, 40.8))
+    pl = torch.from_numpy(np.asarray(g0["frustum"], dtype=np.float32).reshape(5, 4)).to(dev)
+    centre = xf[:, 12:15] + 0.5
+    dist = (centre @ pl[:, :3].T + pl[:, 3]).min(dim=1).values
+    order = torch.argsort((dist > -1.0).to(torch.int32), stable=True)
+    xf = xf[order].contiguous()
 torch.cuda.synchronize()
 stream = torch.cuda.Stream(device=dev)
 ctx = mc.Context(0, stream=stream.cuda_stream)

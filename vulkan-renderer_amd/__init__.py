@@ -46,7 +46,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 TEST_FRUSTUM, TEST_CONE, TEST_HIZ, TEST_ALL = 1, 2, 4, 7
 COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
 CMD_NV_MESHLETS, CMD_EXT_GROUPS = 0, 1
-CULL_NO_INSTANCE_PRECULL = 1
+CULL_NO_INSTANCE_PRECULL, CULL_EXACT_ARITHMETIC, CULL_COUNT_SLOW_PAIRS = 1, 2, 4
 CMD_EXT = np.dtype([("groupCountX", "<u4"), ("groupCountY", "<u4"), ("groupCountZ", "<u4")])
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8
 STATIC_MAX_GROUPS, STATIC_MAX_INSTANCES, STATIC_SCRATCH_BYTES = 2097152, 1048576, 21070592
@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
-    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats",
+    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_slow_path_pairs",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
 ]
@@ -115,6 +115,7 @@ _sig("mcull_hiz_pyramid", _I, [_P, _U32, C.POINTER(_P), C.POINTER(_U64)])
 _sig("mcull_hiz_download_level", _I, [_P, _U32, _U32, _P])
 _sig("mcull_cull", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
 _sig("mcull_cull_static", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
+_sig("mcull_slow_path_pairs", _I, [_P, C.POINTER(_U64)])
 _sig("mcull_precull_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_I)])
 _sig("mcull_rebase_commands", _I, [_P, _P, _U32])
 _sig("mcull_task_payload_count", _U64, [_P])
@@ -169,6 +170,11 @@ _sig("mcull_group_cull", _I, [_P, _P, C.POINTER(CullParams), _P])
 _sig("mcull_group_frame", _I, [_P, _P, _U32, _U32, _U32, _U32, C.POINTER(CullParams), _P])
 _sig("mcull_group_synchronize", _I, [_P])
 _sig("mcull_group_download", _I, [_P, _U32, _P, _U64, _P, _P])
+
+
+def _flags(precull, exact, count_slow):
+    return (0 if precull else CULL_NO_INSTANCE_PRECULL) | (CULL_EXACT_ARITHMETIC if exact else 0) | \
+        (CULL_COUNT_SLOW_PAIRS if count_slow else 0)
 
 
 class McullError(RuntimeError):
@@ -514,10 +520,10 @@ class Context:
     # ---- cull + compact
     def cull(self, globals_, tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
              cmd_stride=0, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
-             total_ptr=None, precull=True):
+             total_ptr=None, precull=True, exact=False, count_slow=False):
         g = np.ascontiguousarray(globals_, dtype=GLOBALS).reshape(1)
         p = CullParams(tests, compaction, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)),
-                       0 if precull else CULL_NO_INSTANCE_PRECULL, list_ptr, list_capacity, commands_ptr, total_ptr)
+                       _flags(precull, exact, count_slow), list_ptr, list_capacity, commands_ptr, total_ptr)
         r = CullResult()
         self._chk(lib.mcull_cull(self._h, _np_ptr(g), C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
@@ -537,11 +543,11 @@ class Context:
 
     def cull_device_globals(self, device_globals_ptr, meshlet_count, tests=TEST_ALL, hiz_view=0, cmd_form=CMD_NV_MESHLETS,
                             cmd_stride=0, cmd_offset=0, write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None,
-                            total_ptr=None, precull=True):
+                            total_ptr=None, precull=True, exact=False, count_slow=False):
         """cull() with the 212-byte Globals in device memory, read when the stream reaches the call: a captured
         HIP graph replays with whatever the buffer then holds.  Ordered compaction only."""
         p = CullParams(tests, COMPACT_ORDERED, hiz_view, cmd_form, cmd_stride, cmd_offset, int(bool(write_mask)),
-                       0 if precull else CULL_NO_INSTANCE_PRECULL, list_ptr, list_capacity, commands_ptr, total_ptr)
+                       _flags(precull, exact, count_slow), list_ptr, list_capacity, commands_ptr, total_ptr)
         r = CullResult()
         self._chk(lib.mcull_cull_device_globals(self._h, device_globals_ptr, meshlet_count, C.byref(p), C.byref(r)))
         self._last = (int(r.n_groups), int(r.n_pairs), cmd_stride)
@@ -560,11 +566,12 @@ class Context:
         P = (CullParams * n)()
         for i in range(n):
             d = dict(tests=TEST_ALL, compaction=COMPACT_ORDERED, hiz_view=0, cmd_form=CMD_NV_MESHLETS, cmd_stride=0, cmd_offset=0,
-                     write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None, total_ptr=None, precull=True)
+                     write_mask=False, list_ptr=None, list_capacity=0, commands_ptr=None, total_ptr=None, precull=True,
+                     exact=False, count_slow=False)
             if params_list is not None:
                 d.update(params_list[i])
             P[i] = CullParams(d["tests"], d["compaction"], d["hiz_view"], d["cmd_form"], d["cmd_stride"], d["cmd_offset"],
-                              int(bool(d["write_mask"])), 0 if d["precull"] else CULL_NO_INSTANCE_PRECULL, d["list_ptr"],
+                              int(bool(d["write_mask"])), _flags(d["precull"], d["exact"], d["count_slow"]), d["list_ptr"],
                               d["list_capacity"], d["commands_ptr"], d["total_ptr"])
         R = (CullResult * n)()
         if device_globals_ptr is None:
@@ -583,6 +590,12 @@ class Context:
 
     def rebase_commands(self, device_totals_ptr, rank):
         self._chk(lib.mcull_rebase_commands(self._h, device_totals_ptr, rank))
+
+    def slow_path_pairs(self):
+        """Pairs of the last cull (run with count_slow=True) that left the fast predicate forms."""
+        n = _U64()
+        self._chk(lib.mcull_slow_path_pairs(self._h, C.byref(n)))
+        return int(n.value)
 
     def precull_stats(self):
         """(marked, tested, per_group) of the last cull's instance pre-cull: instances (or, for scenes with

@@ -64,16 +64,6 @@ struct Xform {
 // per uploaded transform (same expression, same rounding) instead of once per pair.
 __device__ __forceinline__ float xform_scale(float4 c0) { return sqrtf(dot3(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z)); }
 
-// The cone and occlusion tests of one pair whose world-space centre (wx, wy, wz) and radius r are
-// known; `culled` is the frustum test's verdict.  Returns the final verdict.
-// accept = !frustum && !occlusion && !cone (shader.task:101) is a conjunction, so the order of the
-// tests cannot change it, only the cost.  The occlusion test's pyramid read is the one
-// data-dependent memory access; the cone test is arithmetic only (two square roots, two
-// reciprocals).  CONE_FIRST (bounds streamed from HBM, the pass is memory-bound): the cone test
-// runs first and about half the pairs never issue the read (8 views at 8192^2: 11.1 -> 10.3 ms).
-// Otherwise (bounds cache-resident, the pass is arithmetic-bound): the occlusion test runs first,
-// because it empties whole waves, which then skip the cone arithmetic (1 M instances of one
-// mesh: 68 ms against 88 ms with the cone test first).
 // normalize(mat3(model) * cone.xyz) (shader.task:95): independent of the view
 __device__ __forceinline__ float4 world_axis(const Xform &m, float4 a) {
     float ax = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
@@ -83,39 +73,189 @@ __device__ __forceinline__ float4 world_axis(const Xform &m, float4 a) {
     return make_float4(ax * ia, ay * ia, az * ia, a.w);
 }
 
-// AXIS_READY: `a` already holds the world-space unit axis (world_axis), as when several views test the
-// same pair; otherwise it is the meshlet's local axis and is transformed only if the cone test runs.
+// ------------------------------------------------------------------------------------------------
+// Guarded-exact evaluation of the cone and occlusion tests.
+// What must equal the scalar CPU transcription is every DECISION (the selected mip level, the texel, the
+// two comparisons), not every intermediate.  The tests are therefore evaluated first with the hardware's
+// approximate reciprocal and reciprocal square root (v_rcp_f32 / v_rsq_f32, one instruction each, accurate
+// to 1 ulp; the bounds below allow 2) in place of the correctly rounded divisions and square roots (about
+// a dozen instructions each), together with a bound on how far each quantity can lie from the value of the
+// IEEE expression.  Where that bound cannot change a decision the decision stands; the lanes for which it
+// could - a dot product within 1e-5 of the cone boundary, a scaled texture coordinate within the bound of
+// a texel edge, a pixel radius next to a power of two, a depth next to the threshold, anything that is
+// not an ordinary finite number - re-evaluate that quantity with the IEEE expression, behind a wave-wide
+// branch that is not taken when no lane needs it.  Results are bit-identical to the all-IEEE evaluation.
+__device__ __forceinline__ bool ordinary(float x) {  // finite, not near under- or overflow; false for NaN
+    const float a = fabsf(x);
+    return a > 1.0e-18f && a < 1.0e18f;
+}
+
+// lanes of this wave that left the fast path, for the statistics of a cull that asks for them
+__device__ __forceinline__ void note_slow(const ViewConst &v, bool slow) {
+    if (v.slow_pairs) {
+        const uint64_t b = __ballot(slow);
+        if (slow && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(b)) atomicAdd(v.slow_pairs, (unsigned long long)__popcll(b));
+    }
+}
+
+// coneCull (shader.task:37-41) of a pair that is still `live`: dot(axis_w, normalize(cam - centre_w)) < -coneW.
+// AXIS_READY: `a` already holds the world-space unit axis (world_axis, IEEE), as when several views test the
+// same pair; otherwise it is the meshlet's local axis.
+// Fast form: both normalisations with v_rsq_f32.  With |axis| and |view| within roundoff of 1 the dot product
+// differs from the IEEE expression's by less than 2e-6 (two reciprocal square roots at 2 ulp, nine roundings
+// of products and sums of magnitude <= 1), so a margin dot + coneW beyond 1e-5 decides; squared lengths
+// outside [1e-18, 1e18], NaNs and infinities fail the guard.
+template <bool AXIS_READY>
+__device__ __forceinline__ bool cone_culled(const ViewConst &v, const Xform &m, float wx, float wy, float wz, float4 a, bool live) {
+    float nx = a.x, ny = a.y, nz = a.z, ax = a.x, ay = a.y, az = a.z, la = 1.0f;
+    if (!AXIS_READY) {
+        nx = (m.c0.x * a.x + m.c1.x * a.y) + m.c2.x * a.z;
+        ny = (m.c0.y * a.x + m.c1.y * a.y) + m.c2.y * a.z;
+        nz = (m.c0.z * a.x + m.c1.z * a.y) + m.c2.z * a.z;
+        la = dot3(nx, ny, nz, nx, ny, nz);
+        const float ia = __builtin_amdgcn_rsqf(la);
+        ax = nx * ia; ay = ny * ia; az = nz * ia;
+    }
+    const float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
+    const float lv = dot3(vx, vy, vz, vx, vy, vz);
+    const float iv = __builtin_amdgcn_rsqf(lv);
+    const float d = dot3(ax, ay, az, vx * iv, vy * iv, vz * iv);
+    bool culled = d < -a.w;
+    const bool sure = fabsf(d + a.w) > 1.0e-5f && ordinary(lv) && ordinary(la) && !v.force_exact;
+    if (__any(live && !sure)) {
+        if (live && !sure) {  // the IEEE expression
+            if (!AXIS_READY) {
+                const float ia = 1.0f / sqrtf(la);
+                ax = nx * ia; ay = ny * ia; az = nz * ia;
+            }
+            const float ie = 1.0f / sqrtf(lv);
+            culled = dot3(ax, ay, az, vx * ie, vy * ie, vz * ie) < -a.w;
+        }
+        note_slow(v, live && !sure);
+    }
+    return culled;
+}
+
+// the mip level changes at powers of two: is px, known to a relative 2^-20, next to one?  (px <= 0.75: level 0 for certain)
+__device__ __forceinline__ bool near_power_of_two(float px) {
+    const uint32_t mant = __float_as_uint(px) & 0x7fffffu;
+    return px > 0.75f && (mant < 16u || mant > 0x7fffffu - 16u);
+}
+
+// nearest + REPEAT addressing, the common case first: a texel index already inside the level needs no division
+__device__ __forceinline__ uint32_t wrap_texel_fast(float scaled_floor, uint32_t size) {
+    if (!(fabsf(scaled_floor) < 1.0e9f)) return 0u;
+    const int32_t i = (int32_t)scaled_floor;
+    if ((uint32_t)i < size) return (uint32_t)i;
+    int32_t mm = i % (int32_t)size;
+    if (mm < 0) mm += (int32_t)size;
+    return (uint32_t)mm;
+}
+
+// occlusionCull (shader.task:58-77) of a pair that is still `live`, from its clip-space centre (cx, cy, cz, cw)
+// and pr = proj[1][1] * r.
+// Fast form: one v_rcp_f32 of cw instead of four divisions by it.  A quotient q = c * rcp(cw) differs from the
+// correctly rounded c / cw by at most |q| 2^-22 (reciprocal at 1 ulp; 1.25 * 2^-22 at 2 ulp), hence
+//   pixel radius: relative 2^-21 at most  -> certain unless next to a power of two (near_power_of_two);
+//   texel:        tu = q/2 + 1/2 by |q| 2^-23 + |tu| 2^-23, s = tu * width by width 2^-23 (1.5 |q| + 2 |tu|)
+//                 <= E = width 2^-22 (|q| + |tu|)  -> certain when s is farther than E from both neighbouring integers;
+//   depth:        certain when |nz - (d - 0.05)| > |nz| 2^-21.
+// cw outside [1e-18, 1e18] or a numerator beyond 1e18 (or NaN) sends the lane to the divisions for everything.
+__device__ __forceinline__ bool occluded(const ViewConst &v, float cx, float cy, float cz, float cw, float pr, bool live) {
+    const bool plain = ordinary(cw) && fabsf(cx) < 1.0e18f && fabsf(cy) < 1.0e18f && fabsf(cz) < 1.0e18f && fabsf(pr) < 1.0e18f &&
+                       !v.force_exact;
+    const float rc = __builtin_amdgcn_rcpf(cw);
+    bool slow = false;
+    // mip level (shader.task:63, :68-72)
+    float px = ((pr * rc) * 2.0f) * v.tex_max;
+    {
+        const bool unsure = !plain || near_power_of_two(px);
+        if (__any(live && unsure)) {
+            if (unsure) px = ((pr / cw) * 2.0f) * v.tex_max;
+            slow |= unsure;
+        }
+    }
+    const uint32_t mip = mip_level(px, v.levels);
+    // level extents are arithmetic; only the level's offset in the flat pyramid comes from the table
+    const uint32_t lw = max(1u, v.w0 >> mip), lh = max(1u, v.h0 >> mip), lo = v.level_table[32 + mip];
+    const float fw = (float)lw, fh = (float)lh;
+    // texel column (shader.task:62, :65, :74)
+    float nx = cx * rc;
+    float tu = nx * 0.5f + 0.5f;
+    float sx = tu * fw, fx = floorf(sx);
+    {
+        const float e = fw * 2.384185791015625e-7f * (fabsf(nx) + fabsf(tu)), f = sx - fx;  // 2^-22
+        const bool unsure = !plain || !(f > e && f < 1.0f - e);
+        if (__any(live && unsure)) {
+            if (unsure) {
+                nx = cx / cw;
+                tu = nx * 0.5f + 0.5f;
+                fx = floorf(tu * fw);
+            }
+            slow |= unsure;
+        }
+    }
+    // texel row (shader.task:62, :65-66, :74)
+    float ny = cy * rc;
+    float th = ny * 0.5f + 0.5f;
+    float tv = 1.0f - th;
+    float sy = tv * fh, fy = floorf(sy);
+    {
+        // 1 - th adds one more rounding: |ny| 2^-23 + |th| 2^-23 + |tv| 2^-23, times the height, plus the product's
+        const float e = fh * 2.384185791015625e-7f * ((fabsf(ny) + fabsf(th)) + fabsf(tv)), f = sy - fy;
+        const bool unsure = !plain || !(f > e && f < 1.0f - e);
+        if (__any(live && unsure)) {
+            if (unsure) {
+                ny = cy / cw;
+                tv = 1.0f - (ny * 0.5f + 0.5f);
+                fy = floorf(tv * fh);
+            }
+            slow |= unsure;
+        }
+    }
+    const uint32_t tx = wrap_texel_fast(fx, lw), ty = wrap_texel_fast(fy, lh);
+    float d = 0.0f;
+    if (live) d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];  // the one data-dependent read: only for pairs still in the running
+    // depth comparison (shader.task:62, :76)
+    const float thr = d - 0.05f;
+    float nz = cz * rc;
+    {
+        const bool unsure = !plain || !(fabsf(nz - thr) > fabsf(nz) * 4.76837158203125e-7f + 1.0e-37f);  // 2^-21
+        if (__any(live && unsure)) {
+            if (unsure) nz = cz / cw;
+            slow |= unsure;
+        }
+    }
+    if (v.slow_pairs && __any(live && slow)) note_slow(v, live && slow);
+    return nz < thr;
+}
+
+// The cone and occlusion tests of one pair whose world-space centre (wx, wy, wz) and radius r are
+// known; `culled` is the frustum test's verdict.  Returns the final verdict.
+// accept = !frustum && !occlusion && !cone (shader.task:101) is a conjunction, so the order of the
+// tests cannot change it, only the cost.  The occlusion test's pyramid read is the one
+// data-dependent memory access; the cone test is arithmetic only.  CONE_FIRST (bounds streamed from HBM,
+// the pass is memory-bound): the cone test runs first and about half the pairs never issue the read
+// (8 views at 8192^2: 11.1 -> 10.3 ms).  Otherwise (bounds cache-resident, the pass is arithmetic-bound): the
+// occlusion test runs first, because it empties whole waves, which then skip the cone arithmetic (1 M
+// instances of one mesh: 68 ms against 88 ms with the cone test first).
 template <bool CONE_FIRST, bool AXIS_READY = false>
 __device__ __forceinline__ bool cone_and_occlusion(const uint32_t TESTS, const ViewConst &v, const Xform &m, float wx, float wy,
                                                    float wz, float r, float4 a, bool culled) {
     auto cone_test = [&]() {
-        if ((TESTS & MCULL_TEST_CONE) && !culled) {  // coneCull, shader.task:37-41
-            const float4 wa = AXIS_READY ? a : world_axis(m, a);
-            const float ax = wa.x, ay = wa.y, az = wa.z;
-            float vx = v.cam[0] - wx, vy = v.cam[1] - wy, vz = v.cam[2] - wz;
-            const float iv = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
-            vx *= iv; vy *= iv; vz *= iv;
-            culled = dot3(ax, ay, az, vx, vy, vz) < -a.w;
+        if ((TESTS & MCULL_TEST_CONE) && __any(!culled)) {
+            const bool c = cone_culled<AXIS_READY>(v, m, wx, wy, wz, a, !culled);
+            culled |= c;
         }
     };
     if (CONE_FIRST) cone_test();
-    if ((TESTS & MCULL_TEST_HIZ) && !culled) {  // occlusionCull, shader.task:58-77
+    if ((TESTS & MCULL_TEST_HIZ) && __any(!culled)) {
         const float cx = ((v.vp[0] * wx + v.vp[4] * wy) + v.vp[8] * wz) + v.vp[12];
         const float cy = ((v.vp[1] * wx + v.vp[5] * wy) + v.vp[9] * wz) + v.vp[13];
         const float cz = ((v.vp[2] * wx + v.vp[6] * wy) + v.vp[10] * wz) + v.vp[14];
         const float cw = ((v.vp[3] * wx + v.vp[7] * wy) + v.vp[11] * wz) + v.vp[15];
-        const float nx = cx / cw, ny = cy / cw, nz = cz / cw;
-        const float ndc_radius = (v.proj11 * r) / cw;
-        const float tu = nx * 0.5f + 0.5f;
-        const float tv = 1.0f - (ny * 0.5f + 0.5f);
-        const float px = (ndc_radius * 2.0f) * v.tex_max;
-        const uint32_t mip = mip_level(px, v.levels);
-        // level extents are arithmetic; only the level's offset in the flat pyramid comes from the table
-        const uint32_t lw = max(1u, v.w0 >> mip), lh = max(1u, v.h0 >> mip), lo = v.level_table[32 + mip];
-        const uint32_t tx = wrap_texel(floorf(tu * (float)lw), lw);
-        const uint32_t ty = wrap_texel(floorf(tv * (float)lh), lh);
-        const float d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];
-        culled = nz < d - 0.05f;
+        const bool o = occluded(v, cx, cy, cz, cw, v.proj11 * r, !culled);
+        culled |= o;
     }
     if (!CONE_FIRST) cone_test();
     return culled;
@@ -207,8 +347,9 @@ __device__ __forceinline__ Axis2 world_axis2(const Xform &m0, const Xform &m1, f
 }
 #undef MCULL_M2
 
-// AXIS_READY: `axis` holds the unit world-space axes (world_axis2), evaluated once for several views;
-// otherwise they are evaluated here, and only if the cone test runs.
+// AXIS_READY: `axis` holds the unit world-space axes (world_axis2, IEEE), evaluated once for several views;
+// otherwise they are evaluated here, and only if the cone test runs.  The cone and occlusion tests are the
+// guarded-exact forms (cone_culled, occluded): packed arithmetic up to the reciprocals, then per element.
 template <bool CONE_FIRST, bool AXIS_READY>
 __device__ __forceinline__ void tests2(const uint32_t TESTS, const ViewConst &v, const Xform &m0, const Xform &m1, const Centre2 &w,
                                        const Axis2 &axis, float4 a0, float4 a1, bool in0, bool in1, bool &vis0, bool &vis1) {
@@ -224,39 +365,66 @@ __device__ __forceinline__ void tests2(const uint32_t TESTS, const ViewConst &v,
         }
     }
     auto cone_test = [&]() {
-        if ((TESTS & MCULL_TEST_CONE) && !(k0 && k1)) {
-            const Axis2 n = AXIS_READY ? axis : world_axis2(m0, m1, a0, a1);
-            f2v vx = splat(v.cam[0]) - wx, vy = splat(v.cam[1]) - wy, vz = splat(v.cam[2]) - wz;
+        if ((TESTS & MCULL_TEST_CONE) && __any(!(k0 && k1))) {
+            f2v nx, ny, nz, la = splat(1.0f), ax, ay, az;
+            if (AXIS_READY) {
+                ax = axis.x; ay = axis.y; az = axis.z;
+                nx = ax; ny = ay; nz = az;
+            } else {
+                const f2v Ax = {a0.x, a1.x}, Ay = {a0.y, a1.y}, Az = {a0.z, a1.z};
+#define MCULL_M2(col, comp) (f2v{m0.col.comp, m1.col.comp})
+                nx = (MCULL_M2(c0, x) * Ax + MCULL_M2(c1, x) * Ay) + MCULL_M2(c2, x) * Az;
+                ny = (MCULL_M2(c0, y) * Ax + MCULL_M2(c1, y) * Ay) + MCULL_M2(c2, y) * Az;
+                nz = (MCULL_M2(c0, z) * Ax + MCULL_M2(c1, z) * Ay) + MCULL_M2(c2, z) * Az;
+#undef MCULL_M2
+                la = dot3v(nx, ny, nz, nx, ny, nz);
+                const f2v ia = {__builtin_amdgcn_rsqf(la.x), __builtin_amdgcn_rsqf(la.y)};
+                ax = nx * ia; ay = ny * ia; az = nz * ia;
+            }
+            const f2v vx = splat(v.cam[0]) - wx, vy = splat(v.cam[1]) - wy, vz = splat(v.cam[2]) - wz;
             const f2v lv = dot3v(vx, vy, vz, vx, vy, vz);
-            const f2v iv = {1.0f / sqrtf(lv.x), 1.0f / sqrtf(lv.y)};
-            vx *= iv; vy *= iv; vz *= iv;
-            const f2v d = dot3v(n.x, n.y, n.z, vx, vy, vz);
-            if (!k0) k0 = d.x < -a0.w;
-            if (!k1) k1 = d.y < -a1.w;
+            const f2v iv = {__builtin_amdgcn_rsqf(lv.x), __builtin_amdgcn_rsqf(lv.y)};
+            const f2v d = dot3v(ax, ay, az, vx * iv, vy * iv, vz * iv);
+            const f2v cw = {a0.w, a1.w};
+            const f2v margin = d + cw;
+            bool c0 = d.x < -a0.w, c1 = d.y < -a1.w;
+            const bool sure0 = fabsf(margin.x) > 1.0e-5f && ordinary(lv.x) && ordinary(la.x) && !v.force_exact;
+            const bool sure1 = fabsf(margin.y) > 1.0e-5f && ordinary(lv.y) && ordinary(la.y) && !v.force_exact;
+            const bool slow0 = !k0 && !sure0, slow1 = !k1 && !sure1;
+            if (__any(slow0 || slow1)) {  // the IEEE expression for the lanes that need it (see cone_culled)
+                auto exact = [&](float nx_, float ny_, float nz_, float la_, float ax_, float ay_, float az_, float vx_, float vy_,
+                                 float vz_, float lv_, float cw_) {
+                    if (!AXIS_READY) {
+                        const float ia = 1.0f / sqrtf(la_);
+                        ax_ = nx_ * ia; ay_ = ny_ * ia; az_ = nz_ * ia;
+                    }
+                    const float ie = 1.0f / sqrtf(lv_);
+                    return dot3(ax_, ay_, az_, vx_ * ie, vy_ * ie, vz_ * ie) < -cw_;
+                };
+                if (slow0) c0 = exact(nx.x, ny.x, nz.x, la.x, ax.x, ay.x, az.x, vx.x, vy.x, vz.x, lv.x, a0.w);
+                if (slow1) c1 = exact(nx.y, ny.y, nz.y, la.y, ax.y, ay.y, az.y, vx.y, vy.y, vz.y, lv.y, a1.w);
+                note_slow(v, slow0);
+                note_slow(v, slow1);
+            }
+            if (!k0) k0 = c0;
+            if (!k1) k1 = c1;
         }
     };
     if (CONE_FIRST) cone_test();
-    if ((TESTS & MCULL_TEST_HIZ) && !(k0 && k1)) {
+    if ((TESTS & MCULL_TEST_HIZ) && __any(!(k0 && k1))) {
         const f2v px_ = ((splat(v.vp[0]) * wx + splat(v.vp[4]) * wy) + splat(v.vp[8]) * wz) + splat(v.vp[12]);
         const f2v py_ = ((splat(v.vp[1]) * wx + splat(v.vp[5]) * wy) + splat(v.vp[9]) * wz) + splat(v.vp[13]);
         const f2v pz_ = ((splat(v.vp[2]) * wx + splat(v.vp[6]) * wy) + splat(v.vp[10]) * wz) + splat(v.vp[14]);
         const f2v pw_ = ((splat(v.vp[3]) * wx + splat(v.vp[7]) * wy) + splat(v.vp[11]) * wz) + splat(v.vp[15]);
         const f2v pr = splat(v.proj11) * r;
-        const f2v nx = {px_.x / pw_.x, px_.y / pw_.y}, ny = {py_.x / pw_.x, py_.y / pw_.y}, nz = {pz_.x / pw_.x, pz_.y / pw_.y};
-        const f2v ndc_radius = {pr.x / pw_.x, pr.y / pw_.y};
-        const f2v tu = nx * 0.5f + 0.5f;
-        const f2v tv = 1.0f - (ny * 0.5f + 0.5f);
-        const f2v px = (ndc_radius * 2.0f) * v.tex_max;
-        auto occluded = [&](float tu_e, float tv_e, float px_e, float nz_e) {
-            const uint32_t mip = mip_level(px_e, v.levels);
-            const uint32_t lw = max(1u, v.w0 >> mip), lh = max(1u, v.h0 >> mip), lo = v.level_table[32 + mip];
-            const uint32_t tx = wrap_texel(floorf(tu_e * (float)lw), lw);
-            const uint32_t ty = wrap_texel(floorf(tv_e * (float)lh), lh);
-            const float d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];
-            return nz_e < d - 0.05f;
-        };
-        if (!k0) k0 = occluded(tu.x, tv.x, px.x, nz.x);
-        if (!k1) k1 = occluded(tu.y, tv.y, px.y, nz.y);
+        if (__any(!k0)) {
+            const bool o = occluded(v, px_.x, py_.x, pz_.x, pw_.x, pr.x, !k0);
+            if (!k0) k0 = o;
+        }
+        if (__any(!k1)) {
+            const bool o = occluded(v, px_.y, py_.y, pz_.y, pw_.y, pr.y, !k1);
+            if (!k1) k1 = o;
+        }
     }
     if (!CONE_FIRST) cone_test();
     vis0 = !k0;
@@ -486,19 +654,20 @@ __device__ __forceinline__ bool instance_outside(const float4 *__restrict__ tran
     return outside;
 }
 
-// Two output forms.  skip != nullptr (the multi-view pass): one byte per group (ranged scenes) or per
-// instance (uniform scenes), 1 = certainly outside.  Otherwise a WORK LIST for the single-view mask pass
-// (layout above; work[0] is zero on entry).  Each workgroup reserves room for the survivors among its 512
-// instances with one atomic, so the list is ordered inside a workgroup's share and in arrival order
-// between workgroups; the mask pass does not depend on the order.  It then never starts a wave for a group
-// that is not in the list: the ballots of those groups are zeroed beforehand.
+// The pre-pass of a single-view cull: the WORK LIST of the mask pass (layout above; work[0] is zero on entry).
+// Each workgroup reserves room for the survivors among its 512 instances with one atomic, so the list is
+// ordered inside a workgroup's share and in arrival order between workgroups; the mask pass does not depend
+// on the order.  It never starts on a group that is not in the list: the ballots of those groups are zeroed
+// here (zero_mask; scenes with few groups per instance) or by a memset beforehand.
+// The multi-view pass has no such level: with one byte per view and group in front of it, it was slower
+// than without (8 views at 8192^2: 5.35 against 5.14 ms; that pass waits for its pyramid reads, not for
+// arithmetic).
 __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *__restrict__ transforms,
                                                                   const float4 *__restrict__ spheres, uint32_t per_instance_sphere,
                                                                   const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ group_base, uint32_t n_instances,
                                                                   uint32_t groups_per_instance, uint64_t units, PreView pv, const ViewConst *__restrict__ view_dev,
-                                                                  uint8_t *__restrict__ skip, uint32_t *__restrict__ work,
-                                                                  uint64_t *__restrict__ zero_mask) {
+                                                                  uint32_t *__restrict__ work, uint64_t *__restrict__ zero_mask) {
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_base;
     const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
@@ -506,21 +675,6 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
 #pragma unroll
     for (int q = 0; q < kPreItems; q++)
         outside[q] = i0 + q < n_instances ? instance_outside(transforms, spheres, per_instance_sphere, i0 + q, pv, view_dev) : true;
-    if (skip) {  // uniform over the launch
-#pragma unroll
-        for (int q = 0; q < kPreItems; q++) {
-            const uint32_t i = i0 + q;
-            if (i >= n_instances) break;
-            const uint8_t flag = outside[q] ? 1 : 0;
-            if (group_base) {
-                const uint32_t b = group_base[i], e = group_base[i + 1];
-                for (uint32_t g = b; g < e; g++) skip[g] = flag;
-            } else {
-                skip[i] = flag;
-            }
-        }
-        return;
-    }
     uint32_t first[kPreItems], n[kPreItems], mine = 0;
 #pragma unroll
     for (int q = 0; q < kPreItems; q++) {
@@ -559,19 +713,6 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
         }
         pos += n[q];
     }
-}
-
-// Number of set bytes (on request only: the statistics of the last pre-cull).
-__global__ __launch_bounds__(kBlock) void count_bytes_kernel(const uint8_t *__restrict__ bytes, uint64_t n,
-                                                             unsigned long long *__restrict__ out) {
-    __shared__ uint32_t s_sum[kWaves];
-    uint32_t x = 0;
-    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (uint64_t)gridDim.x * kBlock) x += bytes[j] ? 1u : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -717,7 +858,6 @@ struct ViewSet {
     ViewConst v[MCULL_MAX_VIEWS];
     uint64_t *mask[MCULL_MAX_VIEWS];
     uint32_t *tile_counts[MCULL_MAX_VIEWS];
-    const uint8_t *skip[MCULL_MAX_VIEWS];  // the view's instance pre-cull bytes, or nullptr
     uint32_t n;
 };
 
@@ -734,7 +874,6 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     __shared__ float4 s_x[kGroups][4];
     __shared__ float s_scale[kGroups];
     __shared__ uint32_t s_count[MCULL_MAX_VIEWS][kWaves];
-    __shared__ uint32_t s_skip[kGroups];  // bit i: view i's pre-cull marked the group's instance
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t block_g0 = blockIdx.x * kGroups;
@@ -742,11 +881,6 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         const uint32_t g = block_g0 + threadIdx.x;
         GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, vs.v[0].uniform_count);
         if (g >= n_groups) gi.count = 0;
-        uint32_t bits = 0;
-        if (g < n_groups)
-            for (uint32_t i = 0; i < vs.n; i++)
-                if (vs.skip[i] && vs.skip[i][group_rec ? g : gi.inst]) bits |= 1u << i;
-        s_skip[threadIdx.x] = bits;
         s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
     }
     __syncthreads();
@@ -756,15 +890,11 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         if (j == 0) s_scale[k] = xf_scale[s_rec[k].x];
     }
     float4 a[NG], c[NG];
-    uint32_t skip_bits[NG];
-    const uint32_t all_views = (1u << vs.n) - 1u;
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const uint4 r = s_rec[wave * NG + k];
-        skip_bits[k] = __builtin_amdgcn_readfirstlane(s_skip[wave * NG + k]);
         const uint32_t last = r.z ? r.z - 1u : 0u;
-        // a group no view needs moves no bounds: its lanes re-read element 0 (see cull_mask_kernel)
-        const uint32_t id = skip_bits[k] == all_views ? 0u : r.y + (lane < last ? lane : last);
+        const uint32_t id = r.y + (lane < last ? lane : last);
         a[k] = load_bounds<NT>(cone_axis_w + id);
         c[k] = load_bounds<NT>(centre_radius + id);
     }
@@ -804,13 +934,10 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
 #pragma unroll
             for (int k = 0; k < NG; k += 2) {
                 const uint32_t slot = wave * NG + k;
-                bool vis0 = false, vis1 = false;
+                bool vis0, vis1;
                 const uint32_t n0 = s_rec[slot].z, n1 = s_rec[slot + 1].z;
-                const bool live0 = !((skip_bits[k] >> i) & 1u), live1 = !((skip_bits[k + 1] >> i) & 1u);
-                if (live0 || live1)
-                    tests2<NT, true>(v.tests, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], live0 && lane < n0,
-                                     live1 && lane < n1, vis0, vis1);
-                const uint64_t b0 = __ballot(vis0 && live0 && lane < n0), b1 = __ballot(vis1 && live1 && lane < n1);
+                tests2<NT, true>(v.tests, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], lane < n0, lane < n1, vis0, vis1);
+                const uint64_t b0 = __ballot(vis0 && lane < n0), b1 = __ballot(vis1 && lane < n1);
                 if (lane == 0 && n0) mask[block_g0 + slot] = b0;
                 if (lane == 0 && n1) mask[block_g0 + slot + 1] = b1;
                 count += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
@@ -820,8 +947,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
             for (int k = 0; k < NG; k++) {
                 const uint32_t slot = wave * NG + k;
                 const uint32_t n_valid = s_rec[slot].z;
-                bool vis = false;
-                if (!((skip_bits[k] >> i) & 1u)) vis = pair_visible_prepared<NT>(v.tests, v, m[k], wc[k], wa[k]) && (lane < n_valid);
+                const bool vis = pair_visible_prepared<NT>(v.tests, v, m[k], wc[k], wa[k]) && (lane < n_valid);
                 const uint64_t ballot = __ballot(vis);
                 if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
                 count += (uint32_t)__popcll(ballot);
@@ -1203,8 +1329,7 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
 }
 
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
-                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev,
-                                  const uint8_t *const *skips) {
+                                  uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev) {
     ViewSet vs;
     std::memset(&vs, 0, sizeof vs);
     vs.n = n_views;
@@ -1212,7 +1337,6 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
         vs.v[i] = *views[i];
         vs.mask[i] = masks[i];
         vs.tile_counts[i] = tile_counts[i];
-        vs.skip[i] = skips ? skips[i] : nullptr;
     }
     // two groups per wave: each group is evaluated n_views times, which hides the load latency that
     // the single-view kernel hides with four groups in flight
@@ -1301,11 +1425,10 @@ hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges
 
 size_t work_list_bytes(uint64_t units, bool ranged) { return work_rec_offset_words(units) * 4 + (ranged ? units * 16 : 0); }
 
-// Exactly one of skip / work: skip = one byte per group (group_base != nullptr) or per instance; work = a work
-// list of work_list_bytes(groups or instances) whose first word the caller has zeroed; zero_mask (list form,
-// optional): the ballot words, of which the pre-pass zeroes those of the groups it drops.
+// work = work_list_bytes(groups or instances) bytes whose first word the caller has zeroed; zero_mask (optional):
+// the ballot words, of which the pre-pass zeroes those of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
-                                   const ViewConst &v, const ViewConst *view_dev, uint8_t *skip, uint32_t *work, uint64_t *zero_mask,
+                                   const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
                                    hipStream_t st) {
     if (s.n_instances == 0) return hipSuccess;
     PreView pv;
@@ -1313,16 +1436,7 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
     const uint32_t per_block = kBlock * kPreItems;
     hipLaunchKernelGGL(instance_precull_kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kBlock), 0, st, s.transforms,
                        spheres, per_instance_sphere ? 1u : 0u, s.ranges, group_base, s.n_instances, s.groups_per_instance,
-                       group_base ? s.n_groups : (uint64_t)s.n_instances, pv, view_dev, skip, work, zero_mask);
-    return hipGetLastError();
-}
-
-// *out (zeroed by the caller) += number of non-zero bytes
-hipError_t launch_count_bytes(const uint8_t *bytes, uint64_t n, uint64_t *out, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    const uint64_t want = (n + kBlock * 16 - 1) / (kBlock * 16);
-    hipLaunchKernelGGL(count_bytes_kernel, dim3((uint32_t)(want < 1024 ? want : 1024)), dim3(kBlock), 0, st, bytes, n,
-                       (unsigned long long *)out);
+                       group_base ? s.n_groups : (uint64_t)s.n_instances, pv, view_dev, work, zero_mask);
     return hipGetLastError();
 }
 

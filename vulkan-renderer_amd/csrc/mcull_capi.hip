@@ -133,18 +133,18 @@ struct mcull_ctx {
         void *commands = nullptr;
         bool have_mask = false;
         uint64_t n_pairs = 0;
-        // the instance pre-cull of this cull: its work list (single view) or its bytes (one of several views),
-        // over `precull_units` groups (ranged scenes) or instances; both nullptr when it did not run
+        // the instance pre-cull of this cull: its work list over `precull_units` groups (ranged scenes) or
+        // instances; nullptr when it did not run
         const uint32_t *work = nullptr;
-        const uint8_t *skip = nullptr;
         uint64_t precull_units = 0;
     };
     struct ViewOut {
-        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, skip, work;
+        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, work;
         uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
         bool counters_clean = false;   // tile counters are all zero (the mask pass adds into them, the command pass re-zeroes)
         uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
         Last last;                      // description of the last cull (for rebase / downloads / payloads)
+        bool counts_slow_pairs = false; // the last cull counted the pairs that left the fast predicate forms
         bool probe_pending = false;     // a pre-cull ran and its kept count has not been looked at yet
         uint64_t probe_units = 0;
         uint32_t precull_cooldown = 0;  // culls still to go without the pre-cull
@@ -363,7 +363,7 @@ int mcull_destroy(mcull_ctx *c) {
                       &c->range_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
-        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.skip, &o.work})
+        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.work})
             release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -673,8 +673,7 @@ struct CullPlan {
     mcull::CmdLayout lay;
     bool want_mask, two_level, streaming;
     uint32_t n_tiles;
-    uint8_t *skip;              // instance pre-cull of this cull: bytes (multi-view pass) or work list (single view),
-    uint32_t *work;             // both nullptr when it does not run
+    uint32_t *work;             // work list of this cull's instance pre-cull, nullptr when it does not run
     uint64_t precull_units;     // groups (ranged scenes) or instances it decides about
 };
 
@@ -734,6 +733,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     }
     v.tests = p.tests;
     v.uniform_count = plan->uniform_count;
+    v.force_exact = (p.flags & MCULL_CULL_EXACT_ARITHMETIC) ? 1u : 0u;
     if (p.tests & MCULL_TEST_HIZ) {
         const HizSlot &hs = c->hiz[p.hiz_view];
         v.tex_max = (float)(hs.w > hs.h ? hs.w : hs.h);
@@ -744,7 +744,6 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
         v.pyramid = (const float *)hs.pyramid.p;
     }
     plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
-    plan->skip = nullptr;
     plan->work = nullptr;
     plan->precull_units = 0;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
@@ -765,6 +764,11 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     if (plan->want_mask && (rc = ensure(c, o.mask, s.n_groups * 8))) return rc;
     if ((rc = ensure(c, o.total, 256))) return rc;
     plan->total = p.total ? p.total : (uint64_t *)o.total.p;
+    o.counts_slow_pairs = (p.flags & MCULL_CULL_COUNT_SLOW_PAIRS) != 0;
+    if (o.counts_slow_pairs) {  // a spare word of the context-owned count buffer, zero at the start of the cull
+        plan->v.slow_pairs = (unsigned long long *)o.total.p + 16;
+        HIPCHK(c, hipMemsetAsync(plan->v.slow_pairs, 0, 8, c->stream));
+    }
     plan->list = p.list;
     plan->capacity = p.list_capacity;
     if (!plan->list) {
@@ -787,8 +791,9 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
-        bool precull = (p.tests & MCULL_TEST_FRUSTUM) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) && s.n_groups >= c->precull_min_groups;
-        if (precull && !multi_view && c->precull_adaptive) {
+        bool precull = !multi_view && (p.tests & MCULL_TEST_FRUSTUM) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) &&
+                       s.n_groups >= c->precull_min_groups;
+        if (precull && c->precull_adaptive) {
             const size_t slot = (size_t)(&o - c->out);
             if (o.probe_pending) {
                 const uint32_t kept = c->kept_host[slot];
@@ -815,17 +820,12 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 c->spheres_uniform_count = plan->uniform_count;
             }
             plan->precull_units = ranged ? s.n_groups : c->n_instances;
-            if (multi_view) {
-                if ((rc = ensure(c, o.skip, plan->precull_units))) return rc;
-                plan->skip = (uint8_t *)o.skip.p;
-            } else {
-                if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
-                plan->work = (uint32_t *)o.work.p;
-                if (c->precull_adaptive && !o.probe_pending) {
-                    c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
-                    o.probe_pending = true;
-                    o.probe_units = plan->precull_units;
-                }
+            if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
+            plan->work = (uint32_t *)o.work.p;
+            if (c->precull_adaptive && !o.probe_pending) {
+                c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
+                o.probe_pending = true;
+                o.probe_units = plan->precull_units;
             }
         }
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
@@ -862,7 +862,6 @@ void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *r
     o.last.commands = pl.commands;
     o.last.have_mask = pl.want_mask;  // a scene without any group has a mask of zero words
     o.last.n_pairs = pl.n_pairs;
-    o.last.skip = pl.skip;
     o.last.work = pl.work;
     o.last.precull_units = pl.precull_units;
     if (result) {
@@ -916,7 +915,7 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
             if (!inline_zero) HIPCHK(c, hipMemsetAsync(o.mask.p, 0, pl.s.n_groups * 8, c->stream));
             HIPCHK(c, mcull::launch_instance_precull(pl.s, (const float4 *)c->range_spheres.p, c->have_ranges,
                                                      c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl.v, view_dev,
-                                                     nullptr, pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, c->stream));
+                                                     pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, c->stream));
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
                                           c->stream, view_dev, pl.work, c->precull_adaptive ? c->kept_dev : nullptr));
@@ -1052,18 +1051,12 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
         const mcull::ViewConst *vc[MCULL_MAX_VIEWS];
         uint64_t *masks[MCULL_MAX_VIEWS];
         uint32_t *counts[MCULL_MAX_VIEWS];
-        const uint8_t *skips[MCULL_MAX_VIEWS];
         for (uint32_t i = 0; i < n_views; i++) {
             vc[i] = &pl[i].v;
             masks[i] = (uint64_t *)c->out[i].mask.p;
             counts[i] = (uint32_t *)c->out[i].tile_counts.p;
-            skips[i] = pl[i].skip;
-            if (pl[i].skip)
-                HIPCHK(c, mcull::launch_instance_precull(pl[i].s, (const float4 *)c->range_spheres.p, c->have_ranges,
-                                                         c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl[i].v,
-                                                         view_dev ? view_dev + i : nullptr, pl[i].skip, nullptr, nullptr, c->stream));
         }
-        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev, skips));
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev));
         for (uint32_t i = 0; i < n_views; i++)
             if (int rc = launch_ordered_tail(c, c->out[i], pl[i])) return rc;
     }
@@ -1199,6 +1192,17 @@ int mcull_download_mask(mcull_ctx *c, uint64_t *out, uint64_t words) {
     return MCULL_OK;
 }
 
+int mcull_slow_path_pairs(mcull_ctx *c, uint64_t *pairs) {
+    if (!c || !pairs) return MCULL_E_INVALID;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    if (!o.counts_slow_pairs) return fail(c, MCULL_E_STATE, "the last cull did not run with MCULL_CULL_COUNT_SLOW_PAIRS");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(pairs, (uint64_t *)o.total.p + 16, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCULL_OK;
+}
+
 int mcull_precull_stats(mcull_ctx *c, uint64_t *instances_or_groups_marked, uint64_t *bytes_tested, int *per_group) {
     if (!c) return MCULL_E_INVALID;
     mcull_ctx::ViewOut &o = c->out[c->cur];
@@ -1206,21 +1210,12 @@ int mcull_precull_stats(mcull_ctx *c, uint64_t *instances_or_groups_marked, uint
     if (instances_or_groups_marked) *instances_or_groups_marked = 0;
     if (bytes_tested) *bytes_tested = o.last.precull_units;
     if (per_group) *per_group = o.last.scene.group_rec != nullptr;
-    if (!o.last.skip && !o.last.work) return MCULL_OK;  // the pre-cull did not run for this cull
+    if (!o.last.work) return MCULL_OK;  // the pre-cull did not run for this cull
     HIPCHK(c, hipSetDevice(c->device));
-    uint64_t n = 0;
-    if (o.last.work) {  // the list's length is the number of survivors
-        uint32_t kept = 0;
-        HIPCHK(c, hipMemcpyAsync(&kept, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        n = o.last.precull_units - kept;
-    } else {
-        uint64_t *slot = (uint64_t *)o.total.p + 8;  // spare words of the context-owned count buffer
-        HIPCHK(c, hipMemsetAsync(slot, 0, 8, c->stream));
-        HIPCHK(c, mcull::launch_count_bytes(o.last.skip, o.last.precull_units, slot, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&n, slot, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+    uint32_t kept = 0;  // the list's length is the number of survivors
+    HIPCHK(c, hipMemcpyAsync(&kept, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = o.last.precull_units - kept;
     if (instances_or_groups_marked) *instances_or_groups_marked = n;
     return MCULL_OK;
 }

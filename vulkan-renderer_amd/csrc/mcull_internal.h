@@ -29,6 +29,10 @@ struct ViewConst {
     // the flat pyramid (indexed per lane by the selected mip level)
     const uint32_t *level_table;
     const float *pyramid;
+    // the guarded-exact predicates: force_exact != 0 sends every pair through the IEEE expressions (measurements,
+    // tests); slow_pairs != nullptr counts the pairs that had to leave the fast forms
+    uint32_t force_exact;
+    unsigned long long *slow_pairs;
 };
 
 // Scene pointers of one cull launch.
@@ -52,10 +56,9 @@ struct CmdLayout {
 uint32_t tile_count_for(uint64_t n_groups);
 bool needs_tile_offsets(uint64_t n_groups);  // the scatter pass wants one uint64 list offset per tile (scan_tiles_kernel)
 // One pass over the scene for n_views views (ordered path only): views[i] -> masks[i], tile_counts[i].
-// skips: per view, the instance pre-cull's bytes (launch_instance_precull) or nullptr
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st,
-                                  const ViewConst *view_dev = nullptr, const uint8_t *const *skips = nullptr);
+                                  const ViewConst *view_dev = nullptr);
 // work: the instance pre-cull's work list (the pass then covers the listed groups only; the ballots of the others
 // must be zero already) or nullptr; kept_report: where the pass leaves the list's length (device pointer to
 // host-mapped memory) or nullptr
@@ -65,12 +68,11 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st);
-// Exactly one of skip (bytes, the multi-view pass) / work (list, the single-view pass; its first word zeroed by the
-// caller).  zero_mask != nullptr (list form): the pre-pass also zeroes the ballot words of the groups it drops.
+// The single-view pre-pass: `work` = work_list_bytes(...) bytes, first word zeroed by the caller.  zero_mask != nullptr:
+// the pre-pass also zeroes the ballot words of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
-                                   const ViewConst &v, const ViewConst *view_dev, uint8_t *skip, uint32_t *work, uint64_t *zero_mask,
+                                   const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
                                    hipStream_t st);
-hipError_t launch_count_bytes(const uint8_t *bytes, uint64_t n, uint64_t *out, hipStream_t st);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st);
