@@ -267,10 +267,7 @@ def test_multi_view_pass_equals_separate_culls(mc, O, H, ctx, kitten):
     ctx.set_instance_ranges(None, None)
 
 
-def test_config4_full_size(mc, O, H):
-    """The headline workload at its full size: 781 250 instances x 128 unique meshlets = 100 M
-    meshlet-instances generated on the device, frustum + cone, ordered compaction.  Size-independent
-    properties of the whole output plus 512 sampled instances compared with the oracle bit for bit."""
+def _config4_full_size(mc, O, H, tests, flip_y=True, with_pyramid=False):
     import importlib
     import os
     import sys
@@ -287,12 +284,19 @@ def test_config4_full_size(mc, O, H):
     c.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=n_inst * per, mem=mc.MEM_DEVICE, adopt=True)
     c.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
     c.set_instance_ranges(off, cnt)
-    g = H.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=True)
+    w, h = 3840, 2160
+    g = H.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=w, height=h, flip_y=flip_y)
+    view = O.View(g)
+    if with_pyramid:
+        depth = H.synthetic_depth(w, h, 64, 1234)
+        c.hiz_build(depth, view=0)
+        view = O.View(g, O.hiz_build(depth, threads=8), w, h)
     lst = torch.empty((n_inst * per, 2), device=dev, dtype=torch.int32)
     cmds = torch.zeros((n_inst, 2), device=dev, dtype=torch.int32)
-    r = c.cull(g, tests=3, list_ptr=lst.data_ptr(), list_capacity=n_inst * per, commands_ptr=cmds.data_ptr(), write_mask=True)
+    r = c.cull(g, tests=tests, list_ptr=lst.data_ptr(), list_capacity=n_inst * per, commands_ptr=cmds.data_ptr(), write_mask=True)
     total = c.download_count()
-    assert r.n_pairs == 100_000_000 and 0.3 < total / r.n_pairs < 0.7
+    assert r.n_pairs == 100_000_000 and 0.01 < total / r.n_pairs < 0.7
+    assert c.precull_stats()[0] > 100_000, "the instance pre-cull ran and dropped the instances outside the frustum"
     cm = cmds.to(torch.int64)
     assert int(cm[:, 0].sum()) == total
     assert torch.equal(cm[:, 1], torch.cumsum(cm[:, 0], 0) - cm[:, 0])
@@ -308,8 +312,9 @@ def test_config4_full_size(mc, O, H):
     cs, ss = cone[idx].cpu().numpy(), sphere[idx].cpu().numpy()
     ts = np.zeros(len(sample), dtype=O.TRANSFORM)
     ts["model"] = xf[torch.from_numpy(sample).to(dev)].cpu().numpy()
-    ref = O.cull_scene(O.View(g), ts, cone_axis_w=cs, centre_radius=ss,
-                       ranges=((np.arange(len(sample)) * per).astype("<u4"), np.full(len(sample), per, "<u4")), tests=3, threads=8)
+    ref = O.cull_scene(view, ts, cone_axis_w=cs, centre_radius=ss,
+                       ranges=((np.arange(len(sample)) * per).astype("<u4"), np.full(len(sample), per, "<u4")), tests=tests, threads=8)
+    assert ref.total > 1000, "the sample holds visible pairs"
     mask = c.download_mask().reshape(n_inst, per // 64)
     assert np.array_equal(mask[sample].reshape(-1), ref.mask)
     assert np.array_equal(cm[:, 0].cpu().numpy()[sample], ref.commands["taskCount"])
@@ -321,7 +326,29 @@ def test_config4_full_size(mc, O, H):
         want = ref.list[pos: pos + n]
         assert (got[:, 0] == i).all() and np.array_equal(got[:, 1] - i * per, want["meshletID"] - k * per)
         pos += n
+    # the same cull with every pair through the IEEE expressions and without the instance level: the same bytes
+    lst2 = torch.empty_like(lst)
+    cmds2 = torch.zeros_like(cmds)
+    c.cull(g, tests=tests, list_ptr=lst2.data_ptr(), list_capacity=n_inst * per, commands_ptr=cmds2.data_ptr(), write_mask=True,
+           exact=True, precull=False)
+    assert c.download_count() == total and torch.equal(cmds2, cmds) and torch.equal(lst2[:total], lst[:total])
+    assert np.array_equal(c.download_mask().reshape(n_inst, per // 64), mask)
     c.close()
+
+
+def test_config4_full_size(mc, O, H):
+    """The headline workload at its full size: 781 250 instances x 128 unique meshlets = 100 M
+    meshlet-instances generated on the device, frustum + cone, ordered compaction.  Size-independent
+    properties of the whole output plus 512 sampled instances compared with the oracle bit for bit."""
+    _config4_full_size(mc, O, H, tests=3)
+
+
+@pytest.mark.parametrize("flip_y", [True, False], ids=["reference_projection_mip0", "unflipped_real_mips"])
+def test_config4_full_size_with_hiz(mc, O, H, flip_y):
+    """The same scene with the occlusion test on (all three tests of shader.task:101) against a 3840x2160 pyramid:
+    with the reference's projection (level 0 for every pair, shader.task:63 sees a negative radius) and with an
+    unflipped one (real mip levels)."""
+    _config4_full_size(mc, O, H, tests=7, flip_y=flip_y, with_pyramid=True)
 
 
 def test_2_pow_32_visible_pairs_are_reported_not_wrapped(mc, H):
