@@ -539,13 +539,23 @@ def run_cull(env, workload):
     out = None
     if rank == 0:
         k_ms = r["region_ms_per_step"] if world == 1 else r["kernel_ms"]
+        # Algorithmic bytes: 32 B per unique meshlet bound TOUCHED + 64 B per transform + 8 B per command + 8 B per
+        # visible pair (+ 4 B per pair that reaches the occlusion test).  The instance pre-cull drops whole
+        # instances before any of their bounds is touched, so those bounds are not part of the figure the rate is
+        # computed from; the figure with every bound counted (the definition before the pre-cull existed) is
+        # reported beside it as `all_bounds`.
+        pre = r["precull"]
+        dropped = 0.0
+        if pre["tested"] and workload != "config3":  # unique bounds per instance (config 3's bounds are one shared mesh)
+            dropped = 32.0 * (pre["marked"] * 64.0 if pre["unit"] == "groups" else pre["marked"] * float(per))
         if workload == "config5" and not args.separate_views:
             # bounds and transforms are read once for all views; each view writes its own list + commands
-            algo = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in r["vis_views"])
+            algo_all = 32.0 * unique + 64.0 * n_inst + sum(8.0 * n_inst + 8.0 * x for x in r["vis_views"])
         else:
-            algo = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
-        algo += 4.0 * r["hiz_pairs"]  # config 4 with the occlusion test on: one texel per pair that reaches it
-        kernels = "cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel (one step)"
+            algo_all = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
+        algo_all += 4.0 * r["hiz_pairs"]  # config 4 with the occlusion test on: one texel per pair that reaches it
+        algo = algo_all - n_views * dropped
+        kernels = "instance_precull_kernel + cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel (one step)"
         shard_note = ("one %d-instance scene split into %d contiguous shards" % (r["n_scene"], world)) if r["scaling"] == "strong" \
             else ("one whole scene per GPU")
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / max(n_pairs, 1), 4),
@@ -556,6 +566,7 @@ def run_cull(env, workload):
         if workload == "config5":
             w, h = r["hiz_size"]
             algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
+            algo_all += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
             kernels = ("8 x (hiz_rows_kernel + hiz_tile_kernel) + cull_mask_views_kernel + 8 x (scan_tiles_kernel + compact_kernel + emit_commands_kernel)"
                        if not args.separate_views else
                        "8 x (hiz_rows_kernel + hiz_tile_kernel + cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel)")
@@ -577,6 +588,12 @@ def run_cull(env, workload):
         out["roofline"] = roofline(algo, k_ms, kernels, traffic, traffic_src,
                                    kernel_ms_single_call=round(r["kernel_ms"], 4),
                                    bytes_per_pair=round(algo / max(n_pairs * n_views, 1), 2))
+        if dropped:
+            rate = algo_all / (k_ms * 1e-3) / 1e9
+            out["roofline"]["all_bounds"] = {"algorithmic_bytes": int(algo_all), "achieved": round(rate, 1),
+                                             "frac": round(rate / HBM_PEAK_GBS, 4),
+                                             "bounds_bytes_not_touched": int(n_views * dropped),
+                                             "note": "every meshlet bound counted as read, as before the instance pre-cull existed"}
         if world == 1:
             out["roofline"]["measured_device_copy"] = measured_copy_gbs(device)
             out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / out["roofline"]["measured_device_copy"], 4)
@@ -623,7 +640,10 @@ def pmc_traffic(args, workload, n_inst, per):
     """Traffic of one step of the profiled default workload, or None when the workload differs."""
     if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False):
         return None, None
-    return pmc_summary_bytes("r01_bench_config4", ("cull_mask_kernel", "super_sum_kernel", "scan_tiles_kernel", "compact_kernel", "emit_commands_kernel"))
+    if args.no_precull or args.exact:
+        return None, None
+    return pmc_summary_bytes("r02_bench_config4", ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel",
+                                                   "emit_commands_kernel"))
 
 
 def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):

@@ -405,13 +405,15 @@ int mcull_scene_save(const char *path, const mcull_vertex *vertices, uint64_t ve
                      uint64_t meshlet_data_words, const mcull_meshlet *meshlets, uint64_t meshlet_count,
                      const uint32_t *range_offset, const uint32_t *range_count, uint64_t n_ranges);
 /* Header only: the counts a caller needs to size its arrays.  MCULL_E_IO / MCULL_E_INVALID (not
- * a scene file, unknown version, inconsistent sizes). */
+ * a scene file, unknown version, inconsistent sizes, a file shorter or longer than its header says). */
 int mcull_scene_info(const char *path, mcull_scene_counts *out);
-/* Reads every section into caller-allocated arrays sized from mcull_scene_info (a NULL pointer
- * skips that section).  MCULL_E_INVALID when the checksum does not match (the outputs then hold
- * unverified bytes), MCULL_E_IO on a short read. */
-int mcull_scene_load(const char *path, mcull_vertex *vertices, uint32_t *indices, uint32_t *meshlet_data,
-                     mcull_meshlet *meshlets, uint32_t *range_offset, uint32_t *range_count);
+/* Reads every section into caller-allocated arrays sized from mcull_scene_info (a NULL pointer skips that
+ * section).  `expected` is what mcull_scene_info returned when the arrays were sized: a file whose counts or
+ * checksum differ from it by now (replaced in between) is refused with MCULL_E_INVALID before anything is
+ * written.  MCULL_E_INVALID also when the payload's checksum does not match (the outputs then hold unverified
+ * bytes) or the file is not as long as its header says, MCULL_E_IO on a short read. */
+int mcull_scene_load(const char *path, const mcull_scene_counts *expected, mcull_vertex *vertices, uint32_t *indices,
+                     uint32_t *meshlet_data, mcull_meshlet *meshlets, uint32_t *range_offset, uint32_t *range_count);
 /* mcull_scene_load + mcull_upload_meshlets + mcull_upload_geometry + mcull_set_instance_ranges
  * (ranges are cleared when the file holds none). */
 int mcull_scene_upload(mcull_ctx *ctx, const char *path);

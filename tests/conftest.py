@@ -65,7 +65,22 @@ def config1(O):
 
 
 @pytest.fixture(scope="session")
-def ctx(mc):
+def _shared_ctx(mc):
     c = mc.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture()
+def ctx(_shared_ctx):
+    """The session's context (creating one per test would dominate the run time), handed out per test and put
+    back into a known state afterwards whatever the test did or wherever it failed: no instance ranges, no
+    timing, view slot 0 selected by the next cull.  Uploads are each test's own business (every test uploads
+    what it culls)."""
+    yield _shared_ctx
+    try:
+        _shared_ctx.set_instance_ranges(None, None)
+        _shared_ctx.enable_timing(False)
+        _shared_ctx.synchronize()
+    except Exception:  # a context broken by the test fails the next test's own calls, with its own message
+        pass

@@ -79,7 +79,7 @@ def test_scene_cache_round_trip(tmp_path, mc, kitten, bunny):
     (tmp_path / "short.mcs").write_bytes(bytes(raw[:5000]))
     with pytest.raises(mc.McullError) as e:
         mc.load_scene(tmp_path / "short.mcs")
-    assert e.value.status == mc.E_IO
+    assert e.value.status == mc.E_INVALID  # refused from its length, before anything is read
     (tmp_path / "junk.mcs").write_bytes(b"not a scene file" * 10)
     with pytest.raises(mc.McullError) as e:
         mc.scene_info(tmp_path / "junk.mcs")

@@ -40,7 +40,7 @@ calls = {
  "mcull_create": (0, None, None), "mcull_group_create": (None, 1, None),
  "mcull_create_globals": (None, None, None, 45.0, 0.1, 800, 600, 1, 1, None), "mcull_extract_frustum": (None,),
  "mcull_reference_transforms": (1, 42, None), "mcull_create_indirect_buffer": (1, 1, 1, None),
- "mcull_scene_info": (None, None), "mcull_scene_load": (None, None, None, None, None, None, None),
+ "mcull_scene_info": (None, None), "mcull_scene_load": (None, None, None, None, None, None, None, None),
  "mcull_scene_save": (None, None, 0, None, 0, None, 0, None, 0, None, None, 0), "mcull_mesh_load_obj": (None, None),
  "mcull_mesh_from_arrays": (None, 0, None, 0, None, 0, None, 0, None),
 }

@@ -78,3 +78,41 @@ def test_malformed_obj_text(tmp_path, mc, seed):
             assert int(m.meshlets["triangleCount"].sum()) == n_idx // 3
         m.close()
     assert loaded > 5
+
+
+def test_a_header_that_promises_more_than_the_file_holds(tmp_path, mc):
+    """A crafted header whose counts and payload size agree with each other but not with the file: it must be
+    refused from the file's real length, before anybody sizes an allocation from it (2^39 vertices = 12 TiB)."""
+    import ctypes as C
+    import struct
+
+    d = np.load(os.path.join(GOLDEN, "kitten_scene.npz"))
+    path = str(tmp_path / "k.mcs")
+    mc.save_scene(path, d["vertices"].view(mc.VERTEX).reshape(-1), None, d["meshlet_data"], d["meshlets"].view(mc.MESHLET).reshape(-1))
+    raw = bytearray(open(path, "rb").read())
+    pad16 = lambda n: (n + 15) & ~15
+    for nv in (2 ** 39, 2 ** 33 + 5, len(d["vertices"]) + 1):
+        b = bytearray(raw)
+        v, i, w, m, r = struct.unpack_from("<5Q", b, 16)
+        struct.pack_into("<Q", b, 16, nv)
+        struct.pack_into("<Q", b, 56, pad16(nv * 24) + pad16(i * 4) + pad16(w * 4) + pad16(m * 48) + 2 * pad16(r * 4))
+        bad = str(tmp_path / "bad.mcs")
+        open(bad, "wb").write(bytes(b))
+        with pytest.raises(mc.McullError) as e:
+            mc.scene_info(bad)
+        assert e.value.status == mc.E_INVALID
+        with pytest.raises(mc.McullError) as e:
+            mc.load_scene(bad)
+        assert e.value.status == mc.E_INVALID
+        assert mc.lib.mcull_scene_upload(None, bad.encode()) == mc.E_INVALID
+    # a file replaced between sizing and loading: the counts handed back to the loader no longer match
+    info = mc.scene_info(path)
+    small = str(tmp_path / "small.mcs")
+    mc.save_scene(small, d["vertices"].view(mc.VERTEX).reshape(-1)[:100], None, d["meshlet_data"][:64], d["meshlets"].view(mc.MESHLET).reshape(-1)[:2])
+    out = np.zeros(info.vertex_count, mc.VERTEX)
+    rc = mc.lib.mcull_scene_load(small.encode(), C.byref(info), out.ctypes.data_as(C.c_void_p), None, None, None, None, None)
+    assert rc == mc.E_INVALID and not out.view("u1").any(), "nothing was written"
+    # trailing garbage makes the length disagree too
+    open(small, "ab").write(b"\0" * 16)
+    with pytest.raises(mc.McullError):
+        mc.scene_info(small)

@@ -24,13 +24,13 @@ int main(int argc, char **argv) {
     mcull_scene_counts info{}; rc = mcull_scene_info(out.c_str(), &info); printf("info %d %llu\n", rc, (unsigned long long)info.meshlet_count);
     std::vector<mcull_vertex> v(info.vertex_count); std::vector<uint32_t> idx(info.index_count), md(info.meshlet_data_words), ro(info.range_count), rcn(info.range_count);
     std::vector<mcull_meshlet> ml(info.meshlet_count);
-    rc = mcull_scene_load(out.c_str(), v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data()); printf("loadscene %d\n", rc);
+    rc = mcull_scene_load(out.c_str(), &info, v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data()); printf("loadscene %d\n", rc);
     // truncated / corrupt files
     FILE *f = fopen(out.c_str(), "rb"); std::vector<char> buf(1 << 20); size_t got = fread(buf.data(), 1, buf.size(), f); fclose(f);
     for (size_t cut : {size_t(0), size_t(10), size_t(95), size_t(96), size_t(1000), got - 1}) {
         f = fopen(cut_path.c_str(), "wb"); fwrite(buf.data(), 1, cut, f); fclose(f);
         rc = mcull_scene_info(cut_path.c_str(), &info);
-        int rc2 = rc ? rc : mcull_scene_load(cut_path.c_str(), v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data());
+        int rc2 = rc ? rc : mcull_scene_load(cut_path.c_str(), &info, v.data(), idx.data(), md.data(), ml.data(), ro.data(), rcn.data());
         printf("cut %zu -> %d %d\n", cut, rc, rc2);
     }
     mcull_mesh_destroy(m);

@@ -233,7 +233,7 @@ int main(int argc, char **argv) {
     (void)tiles;
     CK(hipMemset(tc, 0, 1 << 20));
     printf("-- cull pass (mask only): group assignment, streaming hint, requests in flight\n");
-#define PRODUCT(NG, NT) timeit("product cull_mask_kernel<3," #NG "," #NT ">", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, NG, NT>), dim3((n_groups + 4 * NG - 1) / (4 * NG)), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr); });
+#define PRODUCT(NG, NT) timeit("product cull_mask_kernel<3," #NG "," #NT ">", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, NG, NT>), dim3((n_groups + 4 * NG - 1) / (4 * NG)), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr); });
     PRODUCT(1, false) PRODUCT(1, true) PRODUCT(2, false) PRODUCT(2, true) PRODUCT(4, false) PRODUCT(4, true) PRODUCT(8, true)
     {
         std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
@@ -242,7 +242,7 @@ int main(int argc, char **argv) {
     }
     printf("-- workgroup -> XCD mapping: round-robin (default) vs one contiguous eighth of the scene per XCD\n");
     PRODUCT(4, true)
-    timeit("product cull_mask_kernel<3,4,true>, XCD-contiguous", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((((n_groups + 15) / 16) + 7) / 8 * 8), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 1u, (const ViewConst *)nullptr); });
+    timeit("product cull_mask_kernel<3,4,true>, XCD-contiguous", [&] { hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((((n_groups + 15) / 16) + 7) / 8 * 8), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 1u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr); });
     PRODUCT(4, true)
     printf("-- layout: the reference's 48-byte AoS records vs two SoA float4 streams\n");
     {
@@ -268,14 +268,14 @@ int main(int argc, char **argv) {
         CK(hipMemset(tc, 0, 1 << 20));
         auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
         timeit("ordered: cull_mask<3,4,nt> + compact<nt> + counter reset", [&] {
-            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr);
-            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
+            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
             zero_tc();
         });
         {   // the same three launches, 20 steps back to back without a host synchronisation in between
             auto one = [&] {
-                hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr);
-                hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
+                hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);
                 zero_tc();
             };
             for (int rep = 0; rep < 3; rep++) {
@@ -288,10 +288,10 @@ int main(int argc, char **argv) {
             }
         }
         // the scatter pass alone on the counters of one cull pass: workgroups per 256-group tile
-        hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr);
-        timeit("compact<nt> alone, 1 workgroup per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u); });
-        timeit("compact<nt> alone, 2 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 2), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 2u); });
-        timeit("compact<nt> alone, 4 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 4), dim3(256), 0, 0, mask, tc, (const uint32_t *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 4u); });
+        hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+        timeit("compact<nt> alone, 1 workgroup per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u); });
+        timeit("compact<nt> alone, 2 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 2), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 2u); });
+        timeit("compact<nt> alone, 4 workgroups per tile", [&] { hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles * 4), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 4u); });
         zero_tc();
         timeit("single pass: one atomic per wavefront", [&] {
             CK(hipMemsetAsync(total, 0, 8)); CK(hipMemsetAsync(inst_count, 0, (size_t)(n_inst + 1) * 4));
@@ -303,7 +303,7 @@ int main(int argc, char **argv) {
         });
         // what a fused single pass could reach: per-group list offsets given, entries written by the cull pass itself
         {
-            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr);
+            hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
             std::vector<uint64_t> hm(n_groups); CK(hipMemcpy(hm.data(), mask, (size_t)n_groups * 8, hipMemcpyDeviceToHost));
             std::vector<uint32_t> ho(n_groups); uint32_t run = 0;
             for (uint32_t g = 0; g < n_groups; g++) { ho[g] = run; run += (uint32_t)__builtin_popcountll(hm[g]); }
@@ -321,7 +321,7 @@ int main(int argc, char **argv) {
             for (int rep = 0; rep < 2; rep++) {
                 for (int i = 0; i < 10; i++) {
                     CK(hipEventRecord(ev[3 * i]));
-                    hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr);
+                    hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
                     CK(hipEventRecord(ev[3 * i + 1]));
                     if (nt) hipLaunchKernelGGL(write_kernel<true>, dim3(2048), dim3(256), 0, 0, wbuf, n8);
                     else hipLaunchKernelGGL(write_kernel<false>, dim3(2048), dim3(256), 0, 0, wbuf, n8);

@@ -16,6 +16,10 @@ if cc:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[k].add(r["Dispatch_Id"])
+    if "--per-launch" in sys.argv:  # raw counter values per launch (memory-side request counters)
+        for k, c in acc.items():
+            print("%-46s launches %3d  " % (k[:46], len(n[k])) + "  ".join("%s %.0f" % (x, v / len(n[k])) for x, v in sorted(c.items())))
+        acc = {}
     for k, c in acc.items():
         w = c.get("SQ_WAVES", 0.0) or 1.0
         print("%-46s launches %3d waves/launch %9d " % (k[:46], len(n[k]), w / len(n[k])) +

@@ -135,7 +135,7 @@ class SceneInfo(C.Structure):
 
 _sig("mcull_scene_save", _I, [C.c_char_p, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, _P, C.c_uint64])
 _sig("mcull_scene_info", _I, [C.c_char_p, C.POINTER(SceneInfo)])
-_sig("mcull_scene_load", _I, [C.c_char_p, _P, _P, _P, _P, _P, _P])
+_sig("mcull_scene_load", _I, [C.c_char_p, C.POINTER(SceneInfo), _P, _P, _P, _P, _P, _P])
 _sig("mcull_scene_upload", _I, [_P, C.c_char_p])
 _sig("mcull_cull_views", _I, [_P, _U32, _P, _P, _P])
 _sig("mcull_cull_views_device_globals", _I, [_P, _U32, _P, _U32, _P, _P])
@@ -270,7 +270,7 @@ def load_scene(path):
     out = {"vertices": np.zeros(info.vertex_count, VERTEX), "indices": np.zeros(info.index_count, "<u4"),
            "meshlet_data": np.zeros(info.meshlet_data_words, "<u4"), "meshlets": np.zeros(info.meshlet_count, MESHLET),
            "range_offset": np.zeros(info.range_count, "<u4"), "range_count": np.zeros(info.range_count, "<u4")}
-    _scene_chk(lib.mcull_scene_load(str(path).encode(), *[_np_ptr(out[k]) for k in
+    _scene_chk(lib.mcull_scene_load(str(path).encode(), C.byref(info), *[_np_ptr(out[k]) for k in
                                                           ("vertices", "indices", "meshlet_data", "meshlets", "range_offset",
                                                            "range_count")]), path)
     return out

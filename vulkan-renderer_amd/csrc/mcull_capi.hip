@@ -464,8 +464,14 @@ static int check_geometry(mcull_ctx *c) {
     if (!c->have_aos) return fail(c, MCULL_E_STATE, "mcull_upload_meshlets has not been called");
     if (!c->have_geometry) return fail(c, MCULL_E_STATE, "mcull_upload_geometry has not been called");
     if (c->geometry_checked) return MCULL_OK;
-    std::vector<mcull_meshlet> ml(c->n_meshlets);
-    std::vector<uint32_t> md(c->n_words);
+    std::vector<mcull_meshlet> ml;
+    std::vector<uint32_t> md;
+    try {  // nothing may throw across the C boundary
+        ml.resize(c->n_meshlets);
+        md.resize(c->n_words);
+    } catch (const std::bad_alloc &) {
+        return fail(c, MCULL_E_NOMEM, "no host memory to check %llu meshlets", (unsigned long long)c->n_meshlets);
+    }
     HIPCHK(c, hipMemcpyAsync(ml.data(), c->aos.p, c->n_meshlets * sizeof(mcull_meshlet), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(md.data(), c->mdata.p, c->n_words * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -541,7 +547,13 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
         return MCULL_OK;
     }
     if (n_instances >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "too many instances");
-    std::vector<uint32_t> rg(2 * n_instances), base(n_instances + 1);
+    std::vector<uint32_t> rg, base;
+    try {  // nothing may throw across the C boundary
+        rg.resize(2 * n_instances);
+        base.resize(n_instances + 1);
+    } catch (const std::bad_alloc &) {
+        return fail(c, MCULL_E_NOMEM, "no host memory for %llu instance ranges", (unsigned long long)n_instances);
+    }
     uint64_t groups = 0, pairs = 0, max_end = 0;
     for (uint64_t i = 0; i < n_instances; i++) {
         rg[2 * i] = meshlet_offset[i];

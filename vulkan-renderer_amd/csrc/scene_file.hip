@@ -12,6 +12,7 @@
 //       u32 range_count[]  (each padded with zeros to a multiple of 16 bytes)
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/mcull.h"
@@ -57,12 +58,23 @@ bool sane(const Header &h) {
            h.range_count < lim;
 }
 
+// The header is believed only when the file really is as long as it says: a header that promises more than
+// the file holds must not size anybody's allocation.  Leaves the stream just behind the header.
 int read_header(FILE *f, Header *h) {
     if (std::fread(h, 1, sizeof *h, f) != sizeof *h) return MCULL_E_IO;
     if (std::memcmp(h->magic, kMagic, 8) != 0 || h->version != kVersion || h->header_bytes != kHeaderBytes || !sane(*h) ||
         h->payload_bytes != payload_bytes(*h))
         return MCULL_E_INVALID;
+    if (std::fseek(f, 0, SEEK_END) != 0) return MCULL_E_IO;
+    const long long size = std::ftell(f);
+    if (size < 0 || std::fseek(f, (long)kHeaderBytes, SEEK_SET) != 0) return MCULL_E_IO;
+    if ((unsigned long long)size != h->payload_bytes + kHeaderBytes) return MCULL_E_INVALID;
     return MCULL_OK;
+}
+
+bool same_counts(const Header &h, const mcull_scene_counts &c) {
+    return h.vertex_count == c.vertex_count && h.index_count == c.index_count && h.meshlet_data_words == c.meshlet_data_words &&
+           h.meshlet_count == c.meshlet_count && h.range_count == c.range_count && h.checksum == c.checksum;
 }
 
 }  // namespace
@@ -132,13 +144,15 @@ int mcull_scene_info(const char *path, mcull_scene_counts *out) {
     return MCULL_OK;
 }
 
-int mcull_scene_load(const char *path, mcull_vertex *vertices, uint32_t *indices, uint32_t *meshlet_data,
-                     mcull_meshlet *meshlets, uint32_t *range_offset, uint32_t *range_count) {
-    if (!path) return MCULL_E_INVALID;
+int mcull_scene_load(const char *path, const mcull_scene_counts *expected, mcull_vertex *vertices, uint32_t *indices,
+                     uint32_t *meshlet_data, mcull_meshlet *meshlets, uint32_t *range_offset, uint32_t *range_count) {
+    if (!path || !expected) return MCULL_E_INVALID;
     FILE *f = std::fopen(path, "rb");
     if (!f) return MCULL_E_IO;
     Header h;
     int rc = read_header(f, &h);
+    // the caller sized its arrays from `expected`: a file that has changed since then must not be read into them
+    if (!rc && !same_counts(h, *expected)) rc = MCULL_E_INVALID;
     if (rc) {
         std::fclose(f);
         return rc;
@@ -155,7 +169,12 @@ int mcull_scene_load(const char *path, mcull_vertex *vertices, uint32_t *indices
         // a section the caller does not want (NULL) is still read: the checksum covers the whole payload
         void *to = d.data;
         if (!to && d.bytes) {
-            skip.resize(d.bytes);
+            try {
+                skip.resize(d.bytes);
+            } catch (const std::bad_alloc &) {
+                std::fclose(f);
+                return MCULL_E_NOMEM;
+            }
             to = skip.data();
         }
         unsigned char pad[16];
@@ -176,10 +195,19 @@ int mcull_scene_upload(mcull_ctx *ctx, const char *path) {
     mcull_scene_counts info;
     int rc = mcull_scene_info(path, &info);
     if (rc) return rc;
-    std::vector<mcull_vertex> v(info.vertex_count);
-    std::vector<uint32_t> md(info.meshlet_data_words), ro(info.range_count), rcount(info.range_count);
-    std::vector<mcull_meshlet> ml(info.meshlet_count);
-    rc = mcull_scene_load(path, v.data(), nullptr, md.data(), ml.data(), ro.data(), rcount.data());
+    std::vector<mcull_vertex> v;
+    std::vector<uint32_t> md, ro, rcount;
+    std::vector<mcull_meshlet> ml;
+    try {  // nothing may throw across the C boundary
+        v.resize(info.vertex_count);
+        md.resize(info.meshlet_data_words);
+        ro.resize(info.range_count);
+        rcount.resize(info.range_count);
+        ml.resize(info.meshlet_count);
+    } catch (const std::bad_alloc &) {
+        return MCULL_E_NOMEM;
+    }
+    rc = mcull_scene_load(path, &info, v.data(), nullptr, md.data(), ml.data(), ro.data(), rcount.data());
     if (rc) return rc;
     if ((rc = mcull_upload_meshlets(ctx, ml.data(), ml.size(), MCULL_MEM_HOST))) return rc;
     if (!v.empty() && (rc = mcull_upload_geometry(ctx, v.data(), v.size(), md.data(), md.size(), MCULL_MEM_HOST))) return rc;
