@@ -155,6 +155,14 @@ def _rank_main(rank, world, port, out_dir):
     lst[: r.total] = torch.from_numpy((r.list.view("<u4").reshape(-1, 2) + np.array([b, 0], dtype="<u4")).view("<i4"))
     packed = D.gather_visible_lists(lst, totals_all)
     np.save(os.path.join(out_dir, "packed_%d.npy" % rank), packed.numpy().view("<u4"))
+    # the same from the lists as the culls write them (drawIDs counted from the shard's first instance)
+    lst_local = torch.zeros((cap, 2), dtype=torch.int32)
+    lst_local[: r.total] = torch.from_numpy(r.list.view("<i4").reshape(-1, 2).copy())
+    firsts = [D.shard_instances(n_inst, world, q)[0] for q in range(world)]
+    packed2 = D.gather_visible_lists(lst_local, totals_all, first_instances=firsts)
+    assert torch.equal(packed2, packed)
+    if world > 1:
+        assert not torch.equal(D.gather_visible_lists(lst_local, totals_all), packed), "rank-local drawIDs overlap"
     # the two-phase frame's exchange: every rank rasterises its own survivors, the images are merged
     w, h = 320, 240
     g2 = H.create_globals(width=w, height=h, meshlet_count=len(ml))

@@ -517,3 +517,25 @@ def test_hostile_arguments_on_a_live_context(mc, kitten, config1):
     assert L.mcull_emit_task_payloads(h, ptr(depth)) == mc.E_STATE
     assert ctx.download_count() > 0
     ctx.close()
+
+
+def test_long_runs_of_empty_instances(mc, O, ctx, kitten, H):
+    """A ranged scene in which almost every instance owns no meshlets (a sharded or LOD scene): the commands of the
+    empty instances carry taskCount 0 and the firstTask of the next instance that owns some."""
+    ml = kitten["meshlets"]
+    n = 120_000
+    t = H.synthetic_transforms(n, extent=3.0, seed=12)
+    off = np.zeros(n, dtype="<u4")
+    cnt = np.zeros(n, dtype="<u4")
+    owners = [0, 1, 40_000, 40_001, 99_999, n - 2]
+    for k, i in enumerate(owners):
+        off[i], cnt[i] = (7 * k) % 50, 65 + 30 * k
+    g = H.create_globals(eye=(6.0, 5.0, 4.0), meshlet_count=0)
+    ref = O.cull_scene(O.View(g), t, ml, ranges=(off, cnt), tests=3)
+    assert ref.total > 0
+    ctx.upload_meshlets(ml)
+    ctx.upload_transforms(t)
+    ctx.set_instance_ranges(off, cnt)
+    ctx.cull(g, tests=3, write_mask=True)
+    assert np.array_equal(ctx.download_mask(), ref.mask)
+    check_against_oracle(mc, ctx, ref, n, mc.COMPACT_ORDERED)

@@ -266,7 +266,7 @@ int main(int argc, char **argv) {
         uint32_t *inst_first, *inst_count; unsigned long long *total;
         CK(hipMalloc(&inst_first, (size_t)(n_inst + 1) * 4)); CK(hipMalloc(&inst_count, (size_t)(n_inst + 1) * 4)); CK(hipMalloc(&total, 256));
         CK(hipMemset(tc, 0, 1 << 20));
-        auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
+        auto zero_tc = [&] { hipLaunchKernelGGL(emit_commands_kernel, dim3((tiles + 255) / 256), dim3(256), 0, 0, (const uint2 *)nullptr, (const uint32_t *)nullptr, 0u, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, 0u, 8u, 0u, 0u, (uint8_t *)nullptr, tc, tiles); };
         timeit("ordered: cull_mask<3,4,nt> + compact<nt> + counter reset", [&] {
             hipLaunchKernelGGL((cull_mask_kernel<3, 4, true>), dim3((n_groups + 15) / 16), dim3(256), 0, 0, cone, sphere, xf, scale, rec, 0u, n_groups, v, mask, tc, 0u, (const ViewConst *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr);
             hipLaunchKernelGGL(compact_kernel<true>, dim3(tiles), dim3(256), 0, 0, mask, tc, (const unsigned long long *)nullptr, rec, 0u, n_groups, list, cap, inst_first, total, 1u);

@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
 // taskCount_i = firstTask of the next non-empty instance (or the total) - firstTask_i.
 // atomic modes: inst_count[] holds visible_i, firstTask = base.
 __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
-    const uint2 *__restrict__ ranges, uint32_t uniform_count, uint32_t n_instances,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ next_nonempty, uint32_t uniform_count, uint32_t n_instances,
     const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
     uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
@@ -1154,8 +1154,9 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
     } else {
         const uint32_t tot = (uint32_t)*total;
         const uint32_t mine = ranges ? ranges[i].y : uniform_count;
-        uint32_t k = i + 1;
-        while (k < n_instances && (ranges ? ranges[k].y : uniform_count) == 0u) k++;
+        // the next instance that owns meshlets: looked up (precomputed with the ranges: a scene with long runs of
+        // empty instances would otherwise cost every thread a walk over the run), or simply the next one
+        const uint32_t k = ranges ? next_nonempty[i] : i + 1u;
         const uint32_t next_first = k < n_instances ? inst_first[k] : tot;
         const uint32_t my_first = mine ? inst_first[i] : next_first;
         task_count = next_first - my_first;
@@ -1396,7 +1397,7 @@ hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const
     const uint32_t work = s.n_instances > n_tiles ? s.n_instances : n_tiles;
     if (work == 0) return hipSuccess;
     const uint32_t grid = (work + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, uniform_count, s.n_instances,
+    hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, s.next_nonempty, uniform_count, s.n_instances,
                        inst_first, inst_count, total, rank_totals, rank, lay.stride, lay.offset, lay.form,
                        (uint8_t *)commands, tile_counts, n_tiles);
     return hipGetLastError();

@@ -412,8 +412,15 @@ int mcull_group_frame(mcull_group *g, const mcull_globals *globals, uint32_t wid
     const uint64_t n_words = (uint64_t)width * height;
     // buffers first (growing one drains the whole group)
     bool regrow = false;
-    for (uint32_t r = 0; r < g->n; r++)
+    for (uint32_t r = 0; r < g->n; r++) {
         regrow |= too_small(g->shard[r].merged, n_words * 4) || (!g->direct && too_small(g->shard[r].peer_depth, n_words * 4 * g->n));
+        // a shard's own depth image is reallocated by its rasteriser when the size changes, while the other
+        // devices may still be merging last frame's image over the links (their wait on all_merged orders
+        // streams, not this thread's hipFree): drain the group before that, too
+        const float *d = nullptr;
+        uint32_t dw = 0, dh = 0;
+        if (mcull_depth_buffer(g->shard[r].ctx, &d, &dw, &dh) == MCULL_OK) regrow |= dw != width || dh != height;
+    }
     if (regrow)
         if (int rc = mcull_group_synchronize(g)) return rc;
     for (uint32_t r = 0; r < g->n; r++) {

@@ -89,7 +89,7 @@ struct mcull_ctx {
     std::string err;
 
     // scene
-    DevBuf aos, cone, sphere, vertices, mdata, transforms, xf_scale, ranges, group_base, group_rec;
+    DevBuf aos, cone, sphere, vertices, mdata, transforms, xf_scale, ranges, group_base, group_rec, next_nonempty;
     uint64_t n_meshlets = 0, n_vertices = 0, n_words = 0, n_instances = 0;
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
     bool geometry_checked = false;  // the uploaded meshlets index only inside the uploaded geometry (host check done)
@@ -359,7 +359,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch,
+                      &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch,
                       &c->range_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
@@ -547,10 +547,11 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
         return MCULL_OK;
     }
     if (n_instances >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "too many instances");
-    std::vector<uint32_t> rg, base;
+    std::vector<uint32_t> rg, base, next;
     try {  // nothing may throw across the C boundary
         rg.resize(2 * n_instances);
         base.resize(n_instances + 1);
+        next.resize(n_instances + 1);
     } catch (const std::bad_alloc &) {
         return fail(c, MCULL_E_NOMEM, "no host memory for %llu instance ranges", (unsigned long long)n_instances);
     }
@@ -566,7 +567,14 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
         if (groups >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "more than 2^32 meshlet groups");
     }
     base[n_instances] = (uint32_t)groups;
+    uint32_t nxt = (uint32_t)n_instances;  // next[i]: the first instance after i that owns meshlets
+    for (uint64_t i = n_instances; i-- > 0;) {
+        next[i] = nxt;
+        if (meshlet_count[i]) nxt = (uint32_t)i;
+    }
     int rc;
+    if ((rc = ensure(c, c->next_nonempty, next.size() * 4))) return rc;
+    if ((rc = copy_in(c, c->next_nonempty.p, next.data(), next.size() * 4, MCULL_MEM_HOST))) return rc;
     if ((rc = ensure(c, c->ranges, rg.size() * 4))) return rc;
     if ((rc = ensure(c, c->group_base, base.size() * 4))) return rc;
     if ((rc = ensure(c, c->group_rec, groups * 16))) return rc;
@@ -722,6 +730,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
                         (unsigned long long)c->ranged_instances, (unsigned long long)c->n_instances);
         if (c->ranged_max_end > c->n_meshlets) return fail(c, MCULL_E_INVALID, "an instance range exceeds the meshlet array");
         s.ranges = (const uint2 *)c->ranges.p;
+        s.next_nonempty = (const uint32_t *)c->next_nonempty.p;
         s.group_rec = (const uint4 *)c->group_rec.p;
         s.groups_per_instance = 0;
         s.n_groups = c->ranged_groups;

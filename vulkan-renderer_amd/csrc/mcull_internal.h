@@ -42,6 +42,7 @@ struct SceneDev {
     const float4 *transforms;     // 4 x float4 (column-major mat4) per instance
     const float *xf_scale;        // length(model[0].xyz) per instance
     const uint2 *ranges;          // {meshletOffset, meshletCount} per instance, or nullptr
+    const uint32_t *next_nonempty;  // with ranges: index of the next instance after i that owns meshlets (n_instances if none)
     const uint4 *group_rec;       // {instance, first meshlet, count, local group} per 64-meshlet group, or nullptr
     uint32_t n_instances;
     uint32_t groups_per_instance; // uniform case

@@ -48,10 +48,16 @@ def gather_draw_list(total_local, cmds_local, rebase, group=None):
     return totals_all, cmds_all
 
 
-def gather_visible_lists(list_local, totals_all, out=None, group=None):
+def gather_visible_lists(list_local, totals_all, out=None, group=None, first_instances=None):
     """Optional third step: one global visible list on every rank.  list_local: int32 tensor
-    [capacity, 2] whose first totals_all[rank] rows are this rank's (drawID, meshletID) entries with
-    rank-local drawIDs; totals_all: the gathered counts.  The shards differ in length, so every rank
+    [capacity, 2] whose first totals_all[rank] rows are this rank's (drawID, meshletID) entries;
+    totals_all: the gathered counts.  A rank's cull numbers its draws from 0 (its shard's first
+    instance), so the drawIDs of different shards overlap: pass first_instances (one value per rank,
+    the global index of that rank's instance 0, e.g. shard_instances(...)[0]) and they are added to
+    column 0 while the shards are packed, which makes the result the list of the unsharded scene.
+    Without it the drawIDs stay as the ranks wrote them (rank-local unless the caller has already made
+    them global), and a consumer has to recover an entry's shard from its position and totals_all.
+    The shards differ in length, so every rank
     contributes max(totals_all) rows (one host read of the counts) and the padding is dropped when
     the shards are packed at their scanned offsets — the offsets the rebased firstTask values refer
     to.  Returns an int32 tensor [sum(totals_all), 2]; `out`, when given, must hold at least that
@@ -70,9 +76,13 @@ def gather_visible_lists(list_local, totals_all, out=None, group=None):
         out = torch.empty((max(total, 1), 2), dtype=list_local.dtype, device=list_local.device)
     elif out.shape[0] < total:
         raise ValueError("out holds %d rows, %d needed" % (out.shape[0], total))
+    if first_instances is not None and len(first_instances) != world:
+        raise ValueError("first_instances needs one value per rank (%d), got %d" % (world, len(first_instances)))
     pos = 0
     for r, c in enumerate(counts):
         out[pos:pos + c] = staged[r * pad:r * pad + c]
+        if first_instances is not None and c:
+            out[pos:pos + c, 0] += int(first_instances[r])
         pos += c
     return out[:total]
 
