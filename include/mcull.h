@@ -328,6 +328,17 @@ int mcull_cull_views_device_globals(mcull_ctx *ctx, uint32_t n_views, const mcul
  * all-gather of every rank's *result.total.  No reference counterpart (single GPU). */
 int mcull_rebase_commands(mcull_ctx *ctx, const uint64_t *device_totals, uint32_t rank);
 
+/* Multi-GPU with ONE collective per frame: every rank lets its cull write the visible count into one extra
+ * record behind its n commands (mcull_cull_params.total = address of record n of the command buffer) and
+ * all-gathers the n + 1 records.  This call then turns the gathered buffer - `world` blocks of
+ * rows_per_rank {taskCount, firstTask} records with rank-local firstTask, each followed by its count record -
+ * into the global description on the device, in one launch on `stream` (a hipStream_t; the call needs no
+ * context: the buffer belongs to the caller's collective): firstTask += the counts of the lower ranks
+ * (modulo 2^32, the field's width), totals[r] = rank r's count, bases[r] = the sum of the counts below r
+ * (device arrays of `world` uint64).  The device must be current.  No reference counterpart (single GPU). */
+int mcull_rebase_gathered_commands(void *stream, void *gathered, uint32_t world, uint64_t rows_per_rank, uint64_t *totals,
+                                   uint64_t *bases);
+
 /* The literal per-32 task payloads of shader.task:28-35,:103-118 for the last ordered
  * mcull_cull: one record per (instance, group of 32 meshlets).  `out` is a device buffer
  * of at least mcull_task_payload_count() records. */

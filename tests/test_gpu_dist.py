@@ -64,3 +64,27 @@ def test_sharded_frame_over_rccl_world_size_one(tmp_path):
     out = subprocess.run([sys.executable, str(script), ROOT, str(port)], capture_output=True, text=True, timeout=110, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "sharded frame ok" in out.stdout
+
+
+@pytest.mark.parametrize("world,rows", [(1, 5), (4, 1001), (8, 1), (3, 200_000)])
+def test_one_launch_rebase_equals_the_tensor_ops(mc, world, rows):
+    """mcull_rebase_gathered_commands against the same arithmetic in tensor operations, on a made-up gathered
+    buffer: counts above 2^32 included, so firstTask wraps and the 64-bit bases do not."""
+    import importlib
+
+    import torch
+
+    D = importlib.import_module("vulkan-renderer_amd.dist")
+    gen = torch.Generator().manual_seed(world * 1000 + rows)
+    g = torch.randint(-(2**31), 2**31 - 1, (world * rows, 2), dtype=torch.int32, generator=gen)
+    counts = torch.randint(0, 2**34, (world,), dtype=torch.int64, generator=gen)
+    gv = g.view(world, rows, 2)
+    gv[:, rows - 1, 0] = ((counts & 0xFFFFFFFF) - ((counts & 0x80000000) << 1)).to(torch.int32)
+    gv[:, rows - 1, 1] = (counts >> 32).to(torch.int32)
+    want_totals, want_cmds = D.rebase_gathered_tensor_ops(g.clone(), world, rows)
+    assert torch.equal(want_totals, counts)
+    dev = g.to("cuda:0")
+    totals, cmds = D.rebase_gathered(dev, world, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(totals.cpu(), want_totals) and torch.equal(cmds.cpu(), want_cmds)
+    assert torch.equal(dev.view(world, rows, 2)[:, rows - 1].cpu(), gv[:, rows - 1]), "the count records stay as gathered"

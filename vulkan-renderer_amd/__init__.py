@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
-    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_slow_path_pairs",
+    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_slow_path_pairs", "mcull_rebase_gathered_commands",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
 ]
@@ -118,6 +118,7 @@ _sig("mcull_cull_static", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResu
 _sig("mcull_slow_path_pairs", _I, [_P, C.POINTER(_U64)])
 _sig("mcull_precull_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_I)])
 _sig("mcull_rebase_commands", _I, [_P, _P, _U32])
+_sig("mcull_rebase_gathered_commands", _I, [_P, _P, _U32, _U64, _P, _P])
 _sig("mcull_task_payload_count", _U64, [_P])
 _sig("mcull_emit_task_payloads", _I, [_P, _P])
 _sig("mcull_download_count", _I, [_P, C.POINTER(_U64)])
@@ -185,6 +186,13 @@ class McullError(RuntimeError):
 
 def version():
     return int(lib.mcull_version())
+
+
+def rebase_gathered_commands(stream, gathered_ptr, world, rows_per_rank, totals_ptr, bases_ptr):
+    """mcull_rebase_gathered_commands on device pointers (the current device's); `stream` is a hipStream_t value."""
+    rc = lib.mcull_rebase_gathered_commands(stream, gathered_ptr, world, rows_per_rank, totals_ptr, bases_ptr)
+    if rc != OK:
+        raise McullError(rc, "rebase_gathered_commands")
 
 
 def hiz_layout(width, height):

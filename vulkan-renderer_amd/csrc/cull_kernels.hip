@@ -1445,6 +1445,40 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU, one collective per frame: `gathered` holds, for each of `world` ranks, `rows` {taskCount, firstTask}
+// records with rank-local firstTask followed by one record that is the rank's visible count (uint64).  Adds to
+// every firstTask the counts of the lower ranks (modulo 2^32, the field's width) and writes the counts and
+// their exclusive prefix to totals[0..world) / bases[0..world): one launch instead of a chain of small ones.
+__global__ __launch_bounds__(kBlock) void rebase_gathered_kernel(uint2 *__restrict__ gathered, uint32_t world, uint64_t rows,
+                                                                 unsigned long long *__restrict__ totals,
+                                                                 unsigned long long *__restrict__ bases) {
+    const uint32_t r = blockIdx.y;
+    unsigned long long base = 0;
+    for (uint32_t q = 0; q < r; q++) {
+        const uint2 c = gathered[(size_t)q * (rows + 1) + rows];
+        base += ((unsigned long long)c.y << 32) | c.x;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint2 c = gathered[(size_t)r * (rows + 1) + rows];
+        totals[r] = ((unsigned long long)c.y << 32) | c.x;
+        bases[r] = base;
+    }
+    uint2 *mine = gathered + (size_t)r * (rows + 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < rows; i += (uint64_t)gridDim.x * kBlock)
+        mine[i].y += (uint32_t)base;
+}
+
+hipError_t launch_rebase_gathered(void *gathered, uint32_t world, uint64_t rows, uint64_t *totals, uint64_t *bases, hipStream_t st) {
+    if (world == 0) return hipSuccess;
+    uint64_t bx = (rows + kBlock * 4 - 1) / (kBlock * 4);
+    if (bx == 0) bx = 1;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(rebase_gathered_kernel, dim3((uint32_t)bx, world), dim3(kBlock), 0, st, (uint2 *)gathered, world, rows,
+                       (unsigned long long *)totals, (unsigned long long *)bases);
+    return hipGetLastError();
+}
+
 hipError_t launch_xform_scale(const float4 *transforms, uint32_t n, float *xf_scale, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(xform_scale_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, transforms, n, xf_scale);

@@ -1129,6 +1129,14 @@ int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t 
     return MCULL_OK;
 }
 
+int mcull_rebase_gathered_commands(void *stream, void *gathered, uint32_t world, uint64_t rows_per_rank, uint64_t *totals,
+                                   uint64_t *bases) {
+    if (!gathered || !totals || !bases || world == 0 || world > 4096) return MCULL_E_INVALID;
+    if (mcull::launch_rebase_gathered(gathered, world, rows_per_rank, totals, bases, (hipStream_t)stream) != hipSuccess)
+        return MCULL_E_HIP;
+    return MCULL_OK;
+}
+
 uint64_t mcull_task_payload_count(const mcull_ctx *c) {
     if (!c) return 0;
     const mcull_ctx::ViewOut &o = c->out[c->cur];
