@@ -507,6 +507,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
             el2, _ = env.timed(lambda k: step(k, gather_lists=True), steps=n2, warmup=1)
             with_lists = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(job_pairs * n_views / (el2 / n2) / 1e9, 3),
                           "list_bytes_per_rank": int(totals_all.max()) * 8 * world}
+    pre_marked, pre_tested, pre_per_group = ctx.precull_stats()  # of the last timed cull (view slot 0)
     hiz_pairs = 0
     if use_hiz and workload == "config4":
         # pairs that reach the occlusion test (one 4-byte texel each in the algorithmic bytes): the survivors
@@ -515,7 +516,6 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                  commands_ptr=cmds[1].data_ptr(), total_ptr=total[1].data_ptr())
         env.fence()
         hiz_pairs = int(total[1].item())
-    pre_marked, pre_tested, pre_per_group = ctx.precull_stats()  # of the last timed cull (view slot 0)
     vis_views = None
     if workload == "config5" and not args.separate_views:
         vis_views = []

@@ -536,22 +536,28 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 // R >= max(|c_m - C| + r_m) (rounded up).  One workgroup per range.  A non-finite centre or radius
 // anywhere in the range, or a range above 2^20 meshlets (one workgroup would take too long), gives
 // R = +inf: such a range is never pre-culled.
+// rmax[i] >= every meshlet radius of the range (what bounds the mip level its meshlets can select); +inf with R,
+// and when a radius of the range is negative (the sign of the projected radius then differs inside the range).
 __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__restrict__ centre_radius,
                                                               const uint2 *__restrict__ ranges, uint32_t uniform_count,
-                                                              float4 *__restrict__ spheres) {
+                                                              float4 *__restrict__ spheres, float *__restrict__ rmax) {
     __shared__ float s_red[kWaves][4];
     const uint32_t i = blockIdx.x;
     const uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (count == 0u || count > (1u << 20)) {
-        if (threadIdx.x == 0) spheres[i] = make_float4(0.0f, 0.0f, 0.0f, count ? __builtin_inff() : 0.0f);
+        if (threadIdx.x == 0) {
+            spheres[i] = make_float4(0.0f, 0.0f, 0.0f, count ? __builtin_inff() : 0.0f);
+            rmax[i] = count ? __builtin_inff() : 0.0f;
+        }
         return;
     }
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, bad = 0.0f;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, bad = 0.0f, neg = 0.0f;
     for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
         const float4 c = centre_radius[first + j];
         sx += c.x; sy += c.y; sz += c.z;
         if (!(fabsf(c.x) < 1.0e18f && fabsf(c.y) < 1.0e18f && fabsf(c.z) < 1.0e18f && fabsf(c.w) < 1.0e18f)) bad = 1.0f;
+        if (c.w < 0.0f) neg = 1.0f;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -567,23 +573,110 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
     bad = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
     __syncthreads();
     // any point works as the centre; what must hold is the radius, measured from the centre as stored
-    float r = 0.0f;
+    float r = 0.0f, rm = 0.0f;
     for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
         const float4 c = centre_radius[first + j];
         const float dx = c.x - cx, dy = c.y - cy, dz = c.z - cz;
         // |c - C| + r, each step rounded to nearest: the factor below covers those roundings
         r = fmaxf(r, sqrtf((dx * dx + dy * dy) + dz * dz) + fabsf(c.w));
+        rm = fmaxf(rm, fabsf(c.w));
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) r = fmaxf(r, __shfl_xor(r, d, 64));
-    if (lane == 0) s_red[wave][0] = r;
+    for (int d = 32; d >= 1; d >>= 1) {
+        r = fmaxf(r, __shfl_xor(r, d, 64));
+        rm = fmaxf(rm, __shfl_xor(rm, d, 64));
+        neg = fmaxf(neg, __shfl_xor(neg, d, 64));
+    }
+    if (lane == 0) { s_red[wave][0] = r; s_red[wave][1] = rm; s_red[wave][2] = neg; }
     __syncthreads();
     if (threadIdx.x == 0) {
         r = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+        rm = fmaxf(fmaxf(s_red[0][1], s_red[1][1]), fmaxf(s_red[2][1], s_red[3][1]));
+        neg = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
         r = r * 1.00001f + 1.0e-30f;
         if (bad != 0.0f || !(r < 1.0e18f)) r = __builtin_inff();
         spheres[i] = make_float4(cx, cy, cz, r);
+        rmax[i] = (neg != 0.0f || !(r < 1.0e18f)) ? __builtin_inff() : rm;
     }
+}
+
+constexpr uint32_t kWorkHeader = 64;  // uint32 words in front of a work list: [0] = number of entries (256-byte header)
+constexpr int kPreItems = 2;          // instances per thread of the pre-pass (one list reservation per 512 instances)
+
+// Layout of a work list over `units` entries: header, then `units` uint32 (ranged scenes: the group's index
+// in the scene; uniform scenes: the surviving instance's index), then - ranged scenes only - `units` uint4
+// group records {instance, first meshlet, count, local group}, 16-byte aligned, so that the mask pass gets a
+// listed group's record with one load instead of two dependent ones.
+__host__ __device__ inline size_t work_rec_offset_words(uint64_t units) { return (kWorkHeader + units + 3) & ~size_t(3); }
+
+// instance_hidden: does the occlusion test certainly reject every meshlet of the instance?
+// A meshlet is rejected when  cz/cw < d - 0.05  for the texel d that its projected centre selects at the mip
+// level its projected radius selects (occlusionCull, shader.task:58-77).  With W the instance sphere's world
+// centre, every meshlet centre w_m (as evaluated in binary32) lies within rho of W, so each clip coordinate of
+// w_m lies within e_k = |row k of VP| rho + roundoff of W's; rmax_w bounds the meshlets' world radii.  From
+// those intervals (cw must stay positive):
+//   depth:  cz/cw <= nz_ub;
+//   level:  at most lmax, the level of the largest possible pixel radius (level 0 when proj[1][1] <= 0: the
+//           radius is then never positive);
+//   texel:  u, v inside [u_lo, u_hi] x [v_lo, v_hi], a sub-range of (0, 1): no REPEAT wrap.  Level l's texel
+//           x = floor(u (w0 >> l)) is the minimum over the level-0 columns [x 2^l, (x+1) 2^l) (the 2x2 reduction
+//           of floor-halved levels nests exactly), and these lie inside [u w0 - 2 2^l, u w0 + 2^l].
+// So every texel any meshlet can select is a minimum over level-0 texels inside a known rectangle, hence not
+// below dmin, the minimum of the texels of one coarser level k that cover the rectangle (at most 4 x 4 reads;
+// levels drop the odd last column and row of their source, so the rectangle must lie inside level k's cover).
+// The instance is hidden when nz_ub < dmin - 0.05f.  That holds as long as no texel is a NaN: the reduction
+// min(x, y) = y < x ? y : x can drop one, and the fine level would then answer "visible" where the coarse one
+// does not.  Word 48 of a pyramid's level table is set by the pyramid kernels when the depth image holds a NaN
+// (and stays set); the instance test is then off for that pyramid.  Anything non-finite or out of range among
+// the intermediate values fails a comparison below, and the instance is not marked.
+__device__ __forceinline__ bool instance_hidden(const ViewConst &v, float wx, float wy, float wz, float rho, float rmax_w) {
+    if (v.level_table[48] != 0u) return false;
+    float c[4], e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float m0 = v.vp[k], m1 = v.vp[4 + k], m2 = v.vp[8 + k], m3 = v.vp[12 + k];
+        c[k] = ((m0 * wx + m1 * wy) + m2 * wz) + m3;
+        const float len = sqrtf((m0 * m0 + m1 * m1) + m2 * m2) * 1.0001f;
+        const float mag = ((fabsf(m0) * (fabsf(wx) + rho) + fabsf(m1) * (fabsf(wy) + rho)) + fabsf(m2) * (fabsf(wz) + rho)) + fabsf(m3);
+        e[k] = len * rho * 1.0001f + mag * 1.52587890625e-5f;  // 2^-16: a thousand times the roundoff of both evaluations
+    }
+    const float cw_lo = c[3] - e[3], cw_hi = c[3] + e[3];
+    if (!(cw_lo > 1.0e-12f && cw_hi < 1.0e18f)) return false;
+    const float r_lo = 1.0f / cw_hi, r_hi = 1.0f / cw_lo;  // 1/cw of any meshlet lies between them
+    auto upper = [&](float x) { return x >= 0.0f ? x * r_hi : x * r_lo; };  // of x / cw
+    auto lower = [&](float x) { return x >= 0.0f ? x * r_lo : x * r_hi; };
+    const float slack = 2.44140625e-4f;  // 2^-12, relative: the roundings of the per-meshlet quotients and sums
+    const float q = upper(c[2] + e[2]);
+    const float nz_ub = q + fabsf(q) * slack + 1.0e-30f;
+    const float nx_lo = lower(c[0] - e[0]), nx_hi = upper(c[0] + e[0]);
+    const float ny_lo = lower(c[1] - e[1]), ny_hi = upper(c[1] + e[1]);
+    const float u_lo = (nx_lo * 0.5f + 0.5f) - (fabsf(nx_lo) + 1.0f) * slack, u_hi = (nx_hi * 0.5f + 0.5f) + (fabsf(nx_hi) + 1.0f) * slack;
+    const float v_lo = (1.0f - (ny_hi * 0.5f + 0.5f)) - (fabsf(ny_hi) + 1.0f) * slack;
+    const float v_hi = (1.0f - (ny_lo * 0.5f + 0.5f)) + (fabsf(ny_lo) + 1.0f) * slack;
+    if (!(u_lo > 0.001f && u_hi < 0.999f && v_lo > 0.001f && v_hi < 0.999f)) return false;
+    uint32_t lmax = 0u;
+    if (!(v.proj11 <= 0.0f)) {
+        const float px_ub = (((v.proj11 * rmax_w) * r_hi) * 2.0f) * v.tex_max * 1.001f;
+        if (!(px_ub < 1.0e9f)) return false;
+        lmax = mip_level(px_ub, v.levels);
+    } else if (!(rmax_w < 1.0e18f)) {
+        return false;
+    }
+    if ((v.w0 >> lmax) == 0u || (v.h0 >> lmax) == 0u || v.w0 > 32768u || v.h0 > 32768u) return false;
+    const int32_t reach = 1 << lmax;
+    int32_t x_lo = (int32_t)floorf(u_lo * (float)v.w0) - 2 * reach - 2, x_hi = (int32_t)(u_hi * (float)v.w0) + reach + 2;
+    int32_t y_lo = (int32_t)floorf(v_lo * (float)v.h0) - 2 * reach - 2, y_hi = (int32_t)(v_hi * (float)v.h0) + reach + 2;
+    x_lo = max(x_lo, 0); y_lo = max(y_lo, 0);
+    x_hi = min(x_hi, (int32_t)v.w0 - 1); y_hi = min(y_hi, (int32_t)v.h0 - 1);
+    uint32_t k = 0;
+    while (k < 16u && (((x_hi >> k) - (x_lo >> k)) > 3 || ((y_hi >> k) - (y_lo >> k)) > 3)) k++;
+    const uint32_t lw = v.w0 >> k, lh = v.h0 >> k;
+    if (k >= 16u || (uint32_t)(x_hi >> k) >= lw || (uint32_t)(y_hi >> k) >= lh) return false;
+    const float *level = v.pyramid + v.level_table[32 + k];
+    float dmin = __builtin_inff();
+    for (int32_t y = y_lo >> k; y <= (y_hi >> k); y++)
+        for (int32_t x = x_lo >> k; x <= (x_hi >> k); x++) dmin = fminf(dmin, level[(size_t)y * lw + x]);
+    return nz_ub < dmin - 0.05f;
 }
 
 // instance_outside: is the instance certainly outside one of the five planes?
@@ -602,21 +695,9 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
 // workgroup-to-segment mapping (ordered, no reservation) - 420 us, the workgroups behind a segment's count
 // still start and leave; one compacted list with one reservation per workgroup of the pre-pass - 392 us,
 // kept.  In each form the pre-pass itself takes 13 - 44 us.
-struct PreView {
-    float frustum[5][4];
-};
-constexpr uint32_t kWorkHeader = 64;  // uint32 words in front of a work list: [0] = number of entries (256-byte header)
-constexpr int kPreItems = 2;          // instances per thread of the pre-pass (one list reservation per 512 instances)
-
-// Layout of a work list over `units` entries: header, then `units` uint32 (ranged scenes: the group's index
-// in the scene; uniform scenes: the surviving instance's index), then - ranged scenes only - `units` uint4
-// group records {instance, first meshlet, count, local group}, 16-byte aligned, so that the mask pass gets a
-// listed group's record with one load instead of two dependent ones.
-__host__ __device__ inline size_t work_rec_offset_words(uint64_t units) { return (kWorkHeader + units + 3) & ~size_t(3); }
-
 __device__ __forceinline__ bool instance_outside(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
-                                                 uint32_t per_instance_sphere, uint32_t i, const PreView &pv,
-                                                 const ViewConst *__restrict__ view_dev) {
+                                                 const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i,
+                                                 const ViewConst &v) {
     const float4 *t = transforms + (size_t)i * 4;
     const float4 c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
     const float4 sp = spheres[per_instance_sphere ? i : 0u];
@@ -639,17 +720,23 @@ __device__ __forceinline__ bool instance_outside(const float4 *__restrict__ tran
     const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
     const float az = ((fabsf(c0.z) * ex + fabsf(c1.z) * ey) + fabsf(c2.z) * ez) + fabsf(c3.z);
     bool outside = false;
+    if (v.tests & MCULL_TEST_FRUSTUM) {
 #pragma unroll
-    for (int p = 0; p < 5; p++) {
-        const float nx = view_dev ? view_dev->frustum[p][0] : pv.frustum[p][0];
-        const float ny = view_dev ? view_dev->frustum[p][1] : pv.frustum[p][1];
-        const float nz = view_dev ? view_dev->frustum[p][2] : pv.frustum[p][2];
-        const float d = view_dev ? view_dev->frustum[p][3] : pv.frustum[p][3];
-        const float nlen = fmaxf(sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
-        const float reach = nlen * F * R;
-        const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
-        const float e = (((nx * wx + ny * wy) + nz * wz) + d) + reach + A * 1.52587890625e-5f;  // 2^-16
-        outside |= e < 0.0f;
+        for (int p = 0; p < 5; p++) {
+            const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2], d = v.frustum[p][3];
+            const float nlen = fmaxf(sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
+            const float reach = nlen * F * R;
+            const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
+            const float e = (((nx * wx + ny * wy) + nz * wz) + d) + reach + A * 1.52587890625e-5f;  // 2^-16
+            outside |= e < 0.0f;
+        }
+    }
+    if ((v.tests & MCULL_TEST_HIZ) && v.pyramid && !outside) {
+        // every meshlet centre, as the per-meshlet path evaluates it, lies within rho of (wx, wy, wz): F R in real
+        // numbers, plus the roundoff of both evaluations (a few 2^-24 of ax + ay + az)
+        const float rho = (F * R) * 1.0001f + ((ax + ay) + az) * 1.52587890625e-5f;
+        const float rmax_w = (rmax[per_instance_sphere ? i : 0u] * F) * 1.0001f;
+        outside = instance_hidden(v, wx, wy, wz, rho, rmax_w);
     }
     return outside;
 }
@@ -666,15 +753,17 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
                                                                   const float4 *__restrict__ spheres, uint32_t per_instance_sphere,
                                                                   const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ group_base, uint32_t n_instances,
-                                                                  uint32_t groups_per_instance, uint64_t units, PreView pv, const ViewConst *__restrict__ view_dev,
+                                                                  uint32_t groups_per_instance, uint64_t units, ViewConst v_arg,
+                                                                  const ViewConst *__restrict__ view_dev, const float *__restrict__ rmax,
                                                                   uint32_t *__restrict__ work, uint64_t *__restrict__ zero_mask) {
+    const ViewConst &v = view_dev ? *view_dev : v_arg;
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_base;
     const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
     bool outside[kPreItems];
 #pragma unroll
     for (int q = 0; q < kPreItems; q++)
-        outside[q] = i0 + q < n_instances ? instance_outside(transforms, spheres, per_instance_sphere, i0 + q, pv, view_dev) : true;
+        outside[q] = i0 + q < n_instances ? instance_outside(transforms, spheres, rmax, per_instance_sphere, i0 + q, v) : true;
     uint32_t first[kPreItems], n[kPreItems], mine = 0;
 #pragma unroll
     for (int q = 0; q < kPreItems; q++) {
@@ -1059,10 +1148,14 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint32_t tile = tile_idx * kTileGroups;
     const uint32_t g_end = min(tile + kTileGroups, n_groups);
     const uint32_t g = tile + threadIdx.x;
+    // A tile without a visible pair (its counter says so: whole instances dropped by the pre-cull or rejected
+    // by the tests) has no entry to write and every ballot word of it is zero: only the list offsets of the
+    // instances that begin in it remain, and they all equal the tile's.
+    const bool empty_tile = tile_counts[tile_idx] == 0u;  // uniform
     uint64_t word = 0;
     uint32_t inst = 0, first = 0, is_first_group = 0;
     if (g < g_end) {
-        word = mask[g];
+        if (!empty_tile) word = mask[g];
         if (group_rec) {
             const uint4 r = group_rec[g];
             inst = r.x; first = r.y; is_first_group = (r.w == 0u);
@@ -1072,6 +1165,10 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
             first = lg * 64u;
             is_first_group = (lg == 0u);
         }
+    }
+    if (empty_tile) {
+        if (g < g_end && is_first_group && threadIdx.x / round_span == part_idx) inst_first[inst] = (uint32_t)running;
+        return;
     }
     uint32_t tile_total;
     const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(word), s_wave, &tile_total);
@@ -1091,6 +1188,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
         const uint32_t round_off = s_off[gbeg];
         const uint32_t round_end = (gbeg + kRoundGroups < n_tile) ? s_off[gbeg + kRoundGroups] : tile_total;
         const uint32_t n_r = round_end - round_off;
+        if (n_r == 0u) continue;  // uniform: nothing of these groups is visible
 #pragma unroll 4
         for (uint32_t j = 0; j < kRoundGroups / kWaves; j++) {
             const uint32_t gidx = gbeg + wave * (kRoundGroups / kWaves) + j;
@@ -1421,10 +1519,14 @@ hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visib
 }
 
 // spheres[i] for ranges[i] (n_ranges of them), or spheres[0] for [0, uniform_count) when ranges == nullptr
+// spheres: n_ranges float4 followed by n_ranges float (range_sphere_bytes)
+size_t range_sphere_bytes(uint32_t n_ranges) { return (size_t)n_ranges * 20; }
+
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st) {
     if (n_ranges == 0) return hipSuccess;
-    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, spheres);
+    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, spheres,
+                       reinterpret_cast<float *>(spheres + n_ranges));
     return hipGetLastError();
 }
 
@@ -1436,12 +1538,11 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
                                    hipStream_t st) {
     if (s.n_instances == 0) return hipSuccess;
-    PreView pv;
-    std::memcpy(pv.frustum, v.frustum, sizeof pv.frustum);
     const uint32_t per_block = kBlock * kPreItems;
+    const float *rmax = reinterpret_cast<const float *>(spheres + (per_instance_sphere ? s.n_instances : 1u));
     hipLaunchKernelGGL(instance_precull_kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kBlock), 0, st, s.transforms,
                        spheres, per_instance_sphere ? 1u : 0u, s.ranges, group_base, s.n_instances, s.groups_per_instance,
-                       group_base ? s.n_groups : (uint64_t)s.n_instances, pv, view_dev, work, zero_mask);
+                       group_base ? s.n_groups : (uint64_t)s.n_instances, v, view_dev, rmax, work, zero_mask);
     return hipGetLastError();
 }
 

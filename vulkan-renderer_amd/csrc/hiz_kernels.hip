@@ -14,6 +14,9 @@
 // that finish last (two tiers of atomic tickets, write-through stores + agent-scope loads).  min() is
 // written as (y < x ? y : x), GLSL's definition, so the result is bit-identical to the
 // level-by-level evaluation for every input including NaN and signed zero.
+// The kernels that read the depth image also report a NaN in it (`nan_seen`, set to 1, never cleared here):
+// that reduction can drop a NaN on the way up, so a coarse level does not bound the finer ones from below
+// when one is present, which the instance-level occlusion test of the cull needs to know.
 #include "mcull_internal.h"
 
 namespace mcull {
@@ -54,10 +57,14 @@ __device__ void reduce_levels_from_global(float *__restrict__ pyr, const uint32_
 __global__ __launch_bounds__(kBlock) void hiz_generic_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                              float *__restrict__ pyr,
                                                              const uint32_t *__restrict__ tbl, uint32_t levels,
-                                                             uint32_t k_begin) {
+                                                             uint32_t k_begin, uint32_t *__restrict__ nan_seen) {
     if (k_begin == 0) {
         const size_t n = (size_t)w * h;
-        for (size_t i = threadIdx.x; i < n; i += kBlock) pyr[i] = depth[i];  // shader.comp:19-21
+        for (size_t i = threadIdx.x; i < n; i += kBlock) {
+            const float d = depth[i];
+            pyr[i] = d;  // shader.comp:19-21
+            if (d != d) *nan_seen = 1u;
+        }
         __syncthreads();
         reduce_levels_from_global(pyr, tbl, 1, levels);
     } else {
@@ -109,7 +116,8 @@ __device__ __forceinline__ float wave_level(float v, uint32_t K, uint32_t levels
 template <bool VEC, bool SINGLE_PASS, bool COPY>
 __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
-                                                          uint32_t levels, uint32_t *__restrict__ counter) {
+                                                          uint32_t levels, uint32_t *__restrict__ counter,
+                                                          uint32_t *__restrict__ nan_seen) {
     __shared__ float s2[16][17];
     const uint32_t t = threadIdx.x, tx = t & 15u, ty = t >> 4;
     const uint32_t x0 = blockIdx.x * kTile + 4 * tx, y0 = blockIdx.y * kTile + 4 * ty;
@@ -133,6 +141,14 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
                 if (COPY && y0 + r < h && x0 + c < w) pyr[(size_t)y * w + x] = p[r][c];
             }
         }
+    }
+    if (COPY) {
+        bool nan = false;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) nan |= p[r][c] != p[r][c];
+        if (nan) *nan_seen = 1u;
     }
     if (levels == 1) return;
 
@@ -253,7 +269,8 @@ constexpr uint64_t kStreamMinTexels = 6ull << 20;
 // Eight rows x 4 texels of one lane: levels 0-3 stored, the level-3 texel returned (both lanes of a pair hold it).
 template <bool VEC>
 __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint32_t w, uint32_t h, float *__restrict__ pyr,
-                                           const uint32_t *__restrict__ tbl, uint32_t x0, uint32_t y0, uint32_t lane) {
+                                           const uint32_t *__restrict__ tbl, uint32_t x0, uint32_t y0, uint32_t lane,
+                                           uint32_t *__restrict__ nan_seen) {
     // ---- level 0: copied out as read (shader.comp:19-21)
     float p[8][4];
     if (VEC) {
@@ -278,6 +295,14 @@ __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint
                 if (y0 + r < h && x0 + c < w) pyr[row + x0 + c] = p[r][c];
             }
         }
+    }
+    {
+        bool nan = false;
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++)
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) nan |= p[r][c] != p[r][c];
+        if (nan) *nan_seen = 1u;
     }
     // ---- level 1: 4 rows x 2 texels
     float q1[4][2];
@@ -333,39 +358,41 @@ __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint
 // shuffle measured slower on large images, in one piece - 114 registers - or as two halves.)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void hiz_rows_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
-                                                          float *__restrict__ pyr, const uint32_t *__restrict__ tbl) {
+                                                          float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
+                                                          uint32_t *__restrict__ nan_seen) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t x0 = blockIdx.x * 256u + 4u * lane;
     const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
     if (y0 >= h) return;  // the whole wave lies below the image
-    hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane);
+    hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane, nan_seen);
 }
 
 template <bool COPY>
 static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                               const uint32_t *level_table, uint32_t *counter, bool single_pass, hipStream_t st) {
+                               const uint32_t *level_table, uint32_t *counter, bool single_pass, uint32_t *nan_seen,
+                               hipStream_t st) {
     const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(src) & 15u) == 0u &&
                      (!COPY || (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u);
     if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
         if (vec)
             hipLaunchKernelGGL((hiz_tile_kernel<true, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                               level_table, levels, counter);
+                               level_table, levels, counter, nan_seen);
         else
             hipLaunchKernelGGL((hiz_tile_kernel<false, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                               level_table, levels, counter);
+                               level_table, levels, counter, nan_seen);
         return hipGetLastError();
     }
     if (vec)
         hipLaunchKernelGGL((hiz_tile_kernel<true, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                           level_table, levels, counter);
+                           level_table, levels, counter, nan_seen);
     else
         hipLaunchKernelGGL((hiz_tile_kernel<false, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                           level_table, levels, counter);
+                           level_table, levels, counter, nan_seen);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (levels > 7) {
-        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, src, w, h, pyramid, level_table, levels, 7u);
+        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, src, w, h, pyramid, level_table, levels, 7u, nan_seen);
         e = hipGetLastError();
     }
     return e;
@@ -377,28 +404,29 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
 // 25.0 us against 22.9 us); 1 = always the latter; 2 = tiles on the depth image with the top levels
 // inside the same launch; 3 = always the streaming pass.
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, int mode, hipStream_t st) {
+                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, int mode, hipStream_t st) {
     if (w < 4 || h < 4) {
         hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, levels,
-                           0u);
+                           0u, nan_seen);
         return hipGetLastError();
     }
     // level 3 must itself be at least 4x4, the tiled kernel's own precondition
     const bool stream = mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels);
     if (!stream || w < 32 || h < 32)
-        return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, st);
+        return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, nan_seen, st);
     constexpr uint32_t base = 3;  // the last level the streaming pass writes
     const dim3 grid((w + 255u) / 256u, (h + 4u * kRowsPerWave - 1u) / (4u * kRowsPerWave));
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
                      (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u;
-    if (vec) hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table);
-    else hipLaunchKernelGGL((hiz_rows_kernel<false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table);
+    if (vec) hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen);
+    else hipLaunchKernelGGL((hiz_rows_kernel<false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || levels <= base + 1u) return e;
     // the tiled kernel with the last level written above as its source: the table pointer and the level count shift
     size_t off = 0;
     for (uint32_t i = 0; i < base; i++) off += (size_t)max(1u, w >> i) * max(1u, h >> i);
-    return launch_tiles<false>(pyramid + off, w >> base, h >> base, pyramid, levels - base, level_table + base, counter, true, st);
+    return launch_tiles<false>(pyramid + off, w >> base, h >> base, pyramid, levels - base, level_table + base, counter, true, nan_seen,
+                               st);
 }
 
 }  // namespace mcull

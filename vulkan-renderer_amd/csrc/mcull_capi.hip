@@ -623,7 +623,10 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
     if (total >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "pyramid exceeds 2^32 texels");
     int rc;
     if ((rc = ensure(c, s.pyramid, total * 4))) return rc;
-    if ((rc = ensure(c, s.table, 48 * 4))) return rc;
+    if (!s.table.p) {  // level table + the slot's "a depth image held a NaN" word, which only the pyramid kernels ever set
+        if ((rc = ensure(c, s.table, mcull::kHizTableWords * 4))) return rc;
+        HIPCHK(c, hipMemsetAsync(s.table.p, 0, mcull::kHizTableWords * 4, c->stream));
+    }
     if (!c->hiz_counter.p) {  // ticket words: zero once; the kernel's last workgroup re-zeroes them
         if ((rc = ensure(c, c->hiz_counter, mcull::kHizCounterBytes))) return rc;
         HIPCHK(c, hipMemsetAsync(c->hiz_counter.p, 0, mcull::kHizCounterBytes, c->stream));
@@ -643,7 +646,7 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
     s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
-                                (uint32_t *)c->hiz_counter.p, c->hiz_mode, c->stream));
+                                (uint32_t *)c->hiz_counter.p, (uint32_t *)s.table.p + mcull::kHizNanWord, c->hiz_mode, c->stream));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;
@@ -812,7 +815,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     if (s.n_groups == 0 || p.compaction != MCULL_COMPACT_ORDERED) {
         if ((rc = ensure(c, o.inst_count, (c->n_instances + 1) * 4))) return rc;
     } else {
-        bool precull = !multi_view && (p.tests & MCULL_TEST_FRUSTUM) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) &&
+        bool precull = !multi_view && (p.tests & (MCULL_TEST_FRUSTUM | MCULL_TEST_HIZ)) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) &&
                        s.n_groups >= c->precull_min_groups;
         if (precull && c->precull_adaptive) {
             const size_t slot = (size_t)(&o - c->out);
@@ -833,7 +836,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             const bool ranged = c->have_ranges;
             if (!c->spheres_valid || c->spheres_ranged != ranged || (!ranged && c->spheres_uniform_count != plan->uniform_count)) {
                 const uint32_t n_ranges = ranged ? (uint32_t)c->n_instances : 1u;
-                if ((rc = ensure(c, c->range_spheres, (size_t)n_ranges * 16))) return rc;
+                if ((rc = ensure(c, c->range_spheres, mcull::range_sphere_bytes(n_ranges)))) return rc;
                 HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, plan->uniform_count,
                                                       (float4 *)c->range_spheres.p, c->stream));
                 c->spheres_valid = true;

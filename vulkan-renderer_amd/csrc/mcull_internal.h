@@ -26,7 +26,8 @@ struct ViewConst {
     uint32_t tests;      // MCULL_TEST_*
     uint32_t uniform_count;  // meshlets per instance when there are no per-instance ranges
     // device table of 3 x 16 uint32: level widths, level heights, float offset of each level in
-    // the flat pyramid (indexed per lane by the selected mip level)
+    // the flat pyramid (indexed per lane by the selected mip level); word 48: non-zero when a depth image
+    // this pyramid slot was built from held a NaN
     const uint32_t *level_table;
     const float *pyramid;
     // the guarded-exact predicates: force_exact != 0 sends every pair through the IEEE expressions (measurements,
@@ -67,6 +68,7 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr, const uint32_t *work = nullptr,
                             uint32_t *kept_report = nullptr);
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
+size_t range_sphere_bytes(uint32_t n_ranges);  // what launch_range_spheres writes: n float4 spheres, then n float largest radii
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st);
 // The single-view pre-pass: `work` = work_list_bytes(...) bytes, first word zeroed by the caller.  zero_mask != nullptr:
@@ -108,10 +110,13 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
                                void *scratch, hipStream_t st, const ViewConst *view_dev = nullptr);
 size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs as `scratch`
 
-// `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero)
+// `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero).
+// `level_table`: kHizTableWords uint32 - 3 x 16 level widths / heights / offsets, then word kHizNanWord, which the
+// launch sets to 1 when the depth image holds a NaN and never clears (`nan_seen` points at it).
 constexpr size_t kHizCounterBytes = 2048;
+constexpr uint32_t kHizTableWords = 64, kHizNanWord = 48;
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, int mode, hipStream_t st);
+                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, int mode, hipStream_t st);
 
 
 }  // namespace mcull
