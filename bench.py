@@ -416,6 +416,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         for v in range(n_views):
             ctx.hiz_build(depth.data_ptr(), view=v, width=w, height=h, mem=mc.MEM_DEVICE)
 
+    if args.tests is not None:  # experiments: a subset of the workload's tests (the pyramids are still built)
+        tests &= args.tests
     # caller-owned outputs (torch owns what the collectives touch); commands and counts are double
     # buffered so that the gather of step k overlaps the cull of step k+1
     cap = n_pairs if workload != "config3" else min(n_pairs, 1 << 30)
@@ -555,6 +557,10 @@ def run_cull(env, workload):
             algo_all = n_views * (32.0 * unique + 64.0 * n_inst + 8.0 * n_inst + 8.0 * visible)
         algo_all += 4.0 * r["hiz_pairs"]  # config 4 with the occlusion test on: one texel per pair that reaches it
         algo = algo_all - n_views * dropped
+        if dropped and r["hiz_pairs"]:
+            # with the instance pre-cull most of those pairs never reach the test; how many do is not counted, so the
+            # figure of the bytes touched leaves the texel reads out altogether (a lower bound of the bytes)
+            algo -= 4.0 * r["hiz_pairs"]
         kernels = "instance_precull_kernel + cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel (one step)"
         shard_note = ("one %d-instance scene split into %d contiguous shards" % (r["n_scene"], world)) if r["scaling"] == "strong" \
             else ("one whole scene per GPU")
@@ -1045,6 +1051,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="config1: also replay the frame as one captured HIP graph")
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-precull", action="store_true", help="cull workloads: switch the instance-level pre-cull off")
+    ap.add_argument("--tests", type=int, default=None, help="cull workloads, experiments: MCULL_TEST_* bits to run instead of the workload's")
     ap.add_argument("--exact", action="store_true",
                     help="cull workloads: every pair through the IEEE expressions instead of the guarded fast forms (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

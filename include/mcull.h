@@ -136,18 +136,26 @@ typedef struct mcull_task_payload {
 #define MCULL_CMD_EXT_GROUPS 1
 
 /* mcull_cull_params.flags.
- * Ordered single-view culls (mcull_cull, mcull_cull_device_globals) that run the frustum test first test ONE
- * enclosing sphere per instance (of the instance's whole meshlet range, computed once after an upload)
- * against the five planes, with a margin
- * that covers the rounding of the per-meshlet expression; the groups of an instance that is certainly
- * outside get zero ballots without a meshlet being loaded or tested.  Results are identical with and
- * without it.  The reference has no such level: it launches every task group of every draw
- * (Engine.cpp:1475-1483, shader.task:79-102).  MCULL_CULL_NO_INSTANCE_PRECULL switches it off
- * (measurements, parity tests); the library also drops it by itself for a while after a cull in which it
- * removed less than a tenth of the scene.  mcull_cull_views and mcull_cull_static have no such level.
- * Bounds that were adopted in place (mcull_upload_bounds_soa with adopt)
- * must be announced again with that call after their contents change: the range spheres are derived
- * from them. */
+ * Ordered single-view culls (mcull_cull, mcull_cull_device_globals) first test ONE enclosing sphere per
+ * instance (of the instance's whole meshlet range, computed once after an upload):
+ *  - with the frustum test on, against the five planes, with a margin that covers the rounding of the
+ *    per-meshlet expression;
+ *  - with the occlusion test on, against the pyramid: the largest depth any meshlet centre of the instance
+ *    can have is compared with the minimum of a few texels of one coarser level that cover every texel any
+ *    of its meshlets could select (at every level their radii could select), with the same bias.
+ * The groups of an instance that one of the two certainly rejects get zero ballots without a meshlet being
+ * loaded or tested.  Results are identical with and without it.  The reference has no such level: it
+ * launches every task group of every draw (Engine.cpp:1475-1483, shader.task:79-102).
+ * The occlusion half relies on the pyramid being the min-reduction of its own level 0 (mcull_hiz_build's
+ * output, not a buffer edited afterwards), and on it holding no NaN: min(x, y) = y < x ? y : x can drop a NaN
+ * on the way up, so a coarse texel then says nothing about the finer ones.  mcull_hiz_build notices a NaN in
+ * the depth image; the occlusion half stays off for that view slot from then on (until the context is
+ * destroyed), the results are unaffected.
+ * MCULL_CULL_NO_INSTANCE_PRECULL switches the level off (measurements, parity tests); the library also drops
+ * it by itself for a while after a cull in which it removed less than a tenth of the scene.
+ * mcull_cull_views and mcull_cull_static have no such level.
+ * Bounds that were adopted in place (mcull_upload_bounds_soa with adopt) must be announced again with that
+ * call after their contents change: the range spheres are derived from them. */
 #define MCULL_CULL_NO_INSTANCE_PRECULL 1u
 /* The cone and occlusion tests are evaluated in a guarded-exact form: first with the hardware's approximate
  * reciprocal / reciprocal square root and an error bound, and with the correctly rounded IEEE expressions
@@ -361,10 +369,11 @@ int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
 int mcull_slow_path_pairs(mcull_ctx *ctx, uint64_t *pairs);
 
 /* What the instance pre-cull of the last cull removed (synchronous; one small counting kernel, run on
- * request only).  *marked = instances marked as certainly outside the frustum (scenes without instance
- * ranges) or 64-meshlet groups of such instances (scenes with ranges: *per_group != 0); *tested = how many
- * instances / groups there were.  0 / 0 when the pre-cull did not run (frustum test off, switched off or
- * backed off, scene below 2048 groups, unordered compaction, one of several views).  No reference counterpart. */
+ * request only).  *marked = instances marked as certainly outside the frustum or certainly occluded (scenes
+ * without instance ranges) or 64-meshlet groups of such instances (scenes with ranges: *per_group != 0);
+ * *tested = how many instances / groups there were.  0 / 0 when the pre-cull did not run (frustum and occlusion
+ * tests both off, switched off or backed off, scene below 65536 groups, unordered compaction, one of several
+ * views).  No reference counterpart. */
 int mcull_precull_stats(mcull_ctx *ctx, uint64_t *marked, uint64_t *tested, int *per_group);
 
 /* Device timestamps around the kernels of each mcull_cull / mcull_hiz_build /

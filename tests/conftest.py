@@ -66,7 +66,17 @@ def config1(O):
 
 @pytest.fixture(scope="session")
 def _shared_ctx(mc):
-    c = mc.Context(0)
+    # the instance pre-cull from 2048 groups on (the library's own threshold is the size from which it pays):
+    # the scenes of the parity tests then run with it, as the large scenes do
+    old = os.environ.get("MCULL_PRECULL_MIN_GROUPS")
+    os.environ["MCULL_PRECULL_MIN_GROUPS"] = "2048"
+    try:
+        c = mc.Context(0)
+    finally:
+        if old is None:
+            del os.environ["MCULL_PRECULL_MIN_GROUPS"]
+        else:
+            os.environ["MCULL_PRECULL_MIN_GROUPS"] = old
     yield c
     c.close()
 

@@ -65,9 +65,9 @@ int main() {
             printf("%4ux%-4u %-52s avg %8.1f us  best %8.1f us  %6.2f TB/s algorithmic\n", w, h, name, sum * 100, best * 1000,
                    algo / (sum / 10 * 1e-3) / 1e12);
         };
-        timeit("streaming pass (levels 0-3) + tiles on level 3", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 0, 0)); });
-        timeit("64x64 tiles, single launch (last-arriver tail)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 2, 0)); });
-        timeit("64x64 tiles + one-workgroup launch for the top", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 1, 0)); });
+        timeit("streaming pass (levels 0-3) + tiles on level 3", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 0, 0)); });
+        timeit("64x64 tiles, single launch (last-arriver tail)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 2, 0)); });
+        timeit("64x64 tiles + one-workgroup launch for the top", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 1, 0)); });
         if (w % 4 == 0)
             timeit("floor: non-temporal copy of level 0 only", [&] {
                 const size_t n4 = (size_t)w * h / 4;
@@ -83,7 +83,7 @@ int main() {
         });
         // the three schemes must agree bit for bit
         std::vector<uint32_t> a(total), b(total);
-        CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 0, 0));
+        CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 0, 0));
         CK(hipMemcpy(a.data(), pyr, total * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), pyr_ref, total * 4, hipMemcpyDeviceToHost));
         printf("%4ux%-4u streaming pass + tiles == per-level result: %s\n", w, h, a == b ? "yes" : "NO");
         CK(hipFree(depth)); CK(hipFree(pyr)); CK(hipFree(pyr_ref)); CK(hipFree(dtbl)); CK(hipFree(counter));

@@ -123,8 +123,8 @@ int main() {
         timeit("tile mapping, L0-2", [&] { hipLaunchKernelGGL(tile_l2, tg, dim3(256), 0, 0, depth, w, h, pyr, dtbl); });
         timeit("wide mapping, L0", [&] { hipLaunchKernelGGL(wide_copy, wg, dim3(256), 0, 0, depth, w, h, pyr); });
         timeit("wide mapping, L0-2", [&] { hipLaunchKernelGGL(wide_l2, wg, dim3(256), 0, 0, depth, w, h, pyr, dtbl); });
-        timeit("product, tiles + top launch", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 1, 0)); });
-        timeit("product, rows + tiles on level 3", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 0, 0)); });
+        timeit("product, tiles + top launch", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 1, 0)); });
+        timeit("product, rows + tiles on level 3", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 0, 0)); });
         CK(hipFree(depth)); CK(hipFree(pyr)); CK(hipFree(dtbl)); CK(hipFree(counter));
     }
     return 0;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(kBlock) void rows_ticket_kernel(const float *__rest
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t x0 = blockIdx.x * 256u + 4u * lane;
     const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
-    if (y0 < h) hiz_rows8<true>(depth, w, h, pyr, tbl, x0, y0, lane, counter + 500);
+    if (y0 < h) hiz_rows8<true>(depth, w, h, pyr, tbl, x0, y0, lane, counter + 500, nullptr, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -53,9 +53,9 @@ int main() {
             printf("%4ux%-4u %-60s avg %8.1f us  best %8.1f us\n", w, h, name, sum * 100, best * 1000);
         };
         const dim3 grid((w + 255u) / 256u, (h + 31u) / 32u);
-        timeit("both launches (the product)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, 0, 0)); });
+        timeit("both launches (the product)", [&] { CK(launch_hiz(depth, w, h, pyr, levels, dtbl, counter, counter + 500, nullptr, 0, 0)); });
         timeit("streaming pass alone (levels 0-3)", [&] {
-            hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, 0, depth, w, h, pyr, dtbl, counter + 500);
+            hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, 0, depth, w, h, pyr, dtbl, counter + 500, nullptr, 0u);
         });
         timeit("streaming pass + drain and region ticket per workgroup", [&] {
             hipLaunchKernelGGL(rows_ticket_kernel, grid, dim3(kBlock), 0, 0, depth, w, h, pyr, dtbl, counter, (w + 511u) / 512u);

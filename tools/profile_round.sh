@@ -1,0 +1,63 @@
+#!/bin/bash
+# The measured evidence of one round, produced on the GPU box: tools/profile_round.sh <tag> [lines|traces|pmc ...]
+# Writes <tag>_bench_<workload>.json (bench lines), <tag>_bench_<workload>_kernel_stats.csv and _summary.json
+# (rocprofv3 kernel trace of the same command, and for the headline the FETCH_SIZE / WRITE_SIZE passes) under
+# gpurun_out/<tag>/; what is to be kept is then copied to profiles/.  Every GPU step has its own time limit and
+# a failing step ends the script.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+T=$1; shift
+WHAT=${*:-lines traces pmc}
+O=$R/gpurun_out/$T
+mkdir -p $O
+line() {
+  local name=$1; shift
+  cd $R
+  timeout -k 10 280 python bench.py "$@" > $O/${T}_bench_$name.json 2> $O/$name.err || { tail -5 $O/$name.err; exit 1; }
+  python3 -c "import json,sys; j=json.load(open(sys.argv[1])); print(sys.argv[2], j['ms_per_step'], 'ms', j['value'], j['unit'], 'frac', j['roofline']['frac'])" $O/${T}_bench_$name.json $name
+}
+trace() {
+  local name=$1; shift
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/kt_$name
+  timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -o p -- python3 $R/bench.py --no-cpu-baseline "$@" > /tmp/kt_$name.log 2>&1 || { tail -5 /tmp/kt_$name.log; exit 1; }
+  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --out-dir $O > /dev/null || exit 1
+  echo "traced $name"
+}
+pmc() {
+  local name=$1; shift
+  cd /tmp && export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${name}_$c
+    timeout -s KILL 120 rocprofv3 --pmc $c --kernel-include-regex "mcull" --output-format csv -d /tmp/pmc_${name}_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; exit 1; }
+    echo "counted $c for $name"
+  done
+  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --fetch /tmp/pmc_${name}_FETCH_SIZE --write /tmp/pmc_${name}_WRITE_SIZE --out-dir $O > /dev/null || exit 1
+}
+for w in $WHAT; do
+  case $w in
+    lines)
+      line config4 || exit 1
+      line config4_hiz_flipped --hiz || exit 1
+      line config4_hiz_unflipped --hiz --unflipped || exit 1
+      line config4_no_precull --no-precull || exit 1
+      line config4_force_dist --force-dist --no-strong-leg || exit 1
+      line config3 --workload config3 --steps 20 --warmup 3 || exit 1
+      line config5 --workload config5 --steps 20 --warmup 3 || exit 1
+      line hiz --workload hiz || exit 1
+      line config1 --workload config1 --graph || exit 1
+      line depth --workload depth || exit 1
+      line bounds --workload bounds || exit 1
+      ;;
+    traces)
+      trace config4 --steps 50 --warmup 10 || exit 1
+      trace config4_hiz_flipped --hiz --steps 50 --warmup 10 || exit 1
+      trace config3 --workload config3 --steps 5 --warmup 2 || exit 1
+      trace config5 --workload config5 --steps 5 --warmup 2 || exit 1
+      ;;
+    pmc)
+      pmc config4 || exit 1
+      ;;
+  esac
+done
+ls $O

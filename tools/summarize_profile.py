@@ -40,8 +40,9 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--prefix", default="mcull::")
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "profiles"))
     args = ap.parse_args()
-    out_dir = os.path.join(ROOT, "profiles")
+    out_dir = args.out_dir
     os.makedirs(out_dir, exist_ok=True)
     summary = {}
     if args.stats and not glob.glob(os.path.join(args.stats, "**", "*kernel_stats.csv"), recursive=True):

@@ -12,8 +12,8 @@
 // Compaction strategies:
 //   ordered      cull_mask_kernel  -> one 64-bit ballot word per group + one count per 256-group tile
 //                scan_tiles_kernel -> (scenes above 1024 tiles) exclusive 64-bit prefix of the tile counts + the
-//                                     total, one workgroup; smaller scenes sum the lower counters inside the
-//                                     scatter pass instead of paying a launch
+//                                     total, one workgroup per 8192 tiles; smaller scenes sum the lower counters
+//                                     inside the scatter pass instead of paying a launch
 //                compact_kernel    -> per-tile block scan + scatter; list sorted by (drawID, meshletID)
 //                emit_commands_kernel -> {taskCount, firstTask} per instance
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
@@ -214,20 +214,32 @@ __device__ __forceinline__ bool occluded(const ViewConst &v, float cx, float cy,
         }
     }
     const uint32_t tx = wrap_texel_fast(fx, lw), ty = wrap_texel_fast(fy, lh);
+    float nz = cz * rc;
+    // Before the texel, the largest depth of the 64 x 8 strip of the depth image that holds its footprint (levels
+    // 0-3: at most 8 x 8 texels, aligned; the table is 1/512 of level 0 and stays in the caches): the texel is not
+    // above it, so a pair whose depth is certainly not below that bound minus the bias is not occluded, whatever
+    // the texel holds, and does not read it.  (A NaN texel compares false in the test itself: visible either way.)
+    bool need = live;
+    if (v.strips) {
+        const bool fine = mip <= 3u;
+        float smax = 0.0f;
+        if (live && fine) smax = v.strips[(size_t)((ty << mip) >> 3) * v.strips_w + ((tx << mip) >> 6)];
+        const bool clear = plain && fine && ((nz - fabsf(nz) * 4.76837158203125e-7f) - 1.0e-37f >= smax - 0.05f);
+        need = live && !clear;
+    }
     float d = 0.0f;
-    if (live) d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];  // the one data-dependent read: only for pairs still in the running
+    if (need) d = v.pyramid[(size_t)lo + (size_t)ty * lw + tx];  // the one data-dependent read: only for pairs still in the running
     // depth comparison (shader.task:62, :76)
     const float thr = d - 0.05f;
-    float nz = cz * rc;
     {
         const bool unsure = !plain || !(fabsf(nz - thr) > fabsf(nz) * 4.76837158203125e-7f + 1.0e-37f);  // 2^-21
-        if (__any(live && unsure)) {
+        if (__any(need && unsure)) {
             if (unsure) nz = cz / cw;
-            slow |= unsure;
+            slow |= need && unsure;
         }
     }
     if (v.slow_pairs && __any(live && slow)) note_slow(v, live && slow);
-    return nz < thr;
+    return need && nz < thr;
 }
 
 // The cone and occlusion tests of one pair whose world-space centre (wx, wy, wz) and radius r are
@@ -1058,55 +1070,69 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // Scenes with more than kScanMinTiles tiles: the list offset of every tile (exclusive 64-bit prefix of the
-// tile counters) and the total, by ONE workgroup that walks the counters 8192 at a time with a running
-// carry (6 104 counters for 100 M pairs: one iteration; 851 000 for 13.9 G pairs: 104).  The scatter pass
-// then starts each tile with one load instead of summing the lower counters itself.
+// tile counters) and the total.  One workgroup per 8192 counters: it first sums every counter below its share
+// (16-byte loads from L2, all threads), then scans its own.  100 M pairs have 6 104 counters, one workgroup;
+// 13.9 G pairs have 851 000, 104 workgroups, of which the last reads 3.4 MB - against one workgroup walking
+// all of them with a running carry, two barriers per 8192, which took 0.50 ms there.  The scatter pass then
+// starts each tile with one load instead of summing the lower counters itself.
 __global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
                                                                 unsigned long long *__restrict__ tile_offsets,
                                                                 unsigned long long *__restrict__ total) {
     constexpr int kScanWaves = kScanBlock / 64;
     __shared__ unsigned long long s_wave[kScanWaves];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * (kScanBlock * kScanPerThread);
     unsigned long long carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += kScanBlock * kScanPerThread) {
-        const uint32_t j0 = base + threadIdx.x * kScanPerThread;
-        uint32_t x[kScanPerThread];
-        if (j0 + kScanPerThread <= n_tiles) {  // counters are 256-byte aligned and j0 is a multiple of 8
-            const uint4 lo = *reinterpret_cast<const uint4 *>(tile_counts + j0);
-            const uint4 hi = *reinterpret_cast<const uint4 *>(tile_counts + j0 + 4);
-            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kScanPerThread; k++) x[k] = j0 + k < n_tiles ? tile_counts[j0 + k] : 0u;
+    if (base) {  // counters are 256-byte aligned and base is a multiple of 8192
+        const uint4 *lower = reinterpret_cast<const uint4 *>(tile_counts);
+        unsigned long long part = 0;
+        for (uint32_t j = threadIdx.x; j < base / 4u; j += kScanBlock) {
+            const uint4 q = lower[j];
+            part += ((unsigned long long)q.x + q.y) + ((unsigned long long)q.z + q.w);
         }
-        unsigned long long sum = 0;
 #pragma unroll
-        for (int k = 0; k < kScanPerThread; k++) sum += x[k];
-        unsigned long long incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long up = __shfl_up(incl, d, 64);
-            if (lane >= (uint32_t)d) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_wave[wave] = part;
         __syncthreads();
-        unsigned long long wave_base = 0, chunk = 0;
 #pragma unroll
-        for (int w = 0; w < kScanWaves; w++) {
-            const unsigned long long t = s_wave[w];
-            if ((uint32_t)w < wave) wave_base += t;
-            chunk += t;
-        }
-        unsigned long long off = carry + wave_base + incl - sum;
-#pragma unroll
-        for (int k = 0; k < kScanPerThread; k++) {
-            if (j0 + k < n_tiles) tile_offsets[j0 + k] = off;
-            off += x[k];
-        }
-        carry += chunk;
-        __syncthreads();  // s_wave is rewritten by the next iteration
+        for (int w = 0; w < kScanWaves; w++) carry += s_wave[w];
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    const uint32_t j0 = base + threadIdx.x * kScanPerThread;
+    uint32_t x[kScanPerThread];
+    if (j0 + kScanPerThread <= n_tiles) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(tile_counts + j0);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(tile_counts + j0 + 4);
+        x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; k++) x[k] = j0 + k < n_tiles ? tile_counts[j0 + k] : 0u;
+    }
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) sum += x[k];
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wave_base = 0, chunk = 0;
+#pragma unroll
+    for (int w = 0; w < kScanWaves; w++) {
+        const unsigned long long t = s_wave[w];
+        if ((uint32_t)w < wave) wave_base += t;
+        chunk += t;
+    }
+    unsigned long long off = carry + wave_base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; k++) {
+        if (j0 + k < n_tiles) tile_offsets[j0 + k] = off;
+        off += x[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry + chunk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1472,7 +1498,8 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
     const uint32_t grid = tiles * split;
     const unsigned long long *offs = (const unsigned long long *)tile_offsets;
     if (tile_offsets) {
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kScanBlock), 0, st, tile_counts, tiles,
+        const uint32_t per_block = kScanBlock * kScanPerThread;
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3((tiles + per_block - 1u) / per_block), dim3(kScanBlock), 0, st, tile_counts, tiles,
                            (unsigned long long *)tile_offsets, (unsigned long long *)total);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

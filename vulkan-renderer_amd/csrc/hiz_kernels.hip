@@ -270,7 +270,7 @@ constexpr uint64_t kStreamMinTexels = 6ull << 20;
 template <bool VEC>
 __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint32_t w, uint32_t h, float *__restrict__ pyr,
                                            const uint32_t *__restrict__ tbl, uint32_t x0, uint32_t y0, uint32_t lane,
-                                           uint32_t *__restrict__ nan_seen) {
+                                           uint32_t *__restrict__ nan_seen, float *__restrict__ strips, uint32_t strips_w) {
     // ---- level 0: copied out as read (shader.comp:19-21)
     float p[8][4];
     if (VEC) {
@@ -303,6 +303,20 @@ __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) nan |= p[r][c] != p[r][c];
         if (nan) *nan_seen = 1u;
+    }
+    // ---- the LARGEST depth of each 64 x 8 strip of the image (16 lanes wide, this wave's 8 rows): what the
+    // occlusion test looks at before it reads a texel of levels 0-3, whose footprint lies inside one strip -
+    // a pair not behind the strip's largest depth is not behind any texel of it.  Rows and columns read
+    // clamped belong to the same strip; lanes wholly past the right edge stay out.  fmaxf skips NaNs.
+    if (strips) {
+        float mx = -__builtin_inff();
+        if (x0 < w) {
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) mx = fmaxf(fmaxf(mx, fmaxf(p[r][0], p[r][1])), fmaxf(p[r][2], p[r][3]));
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        if ((lane & 15u) == 0u && x0 < w) strips[(size_t)(y0 >> 3) * strips_w + (x0 >> 6)] = mx;
     }
     // ---- level 1: 4 rows x 2 texels
     float q1[4][2];
@@ -359,12 +373,13 @@ __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void hiz_rows_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
-                                                          uint32_t *__restrict__ nan_seen) {
+                                                          uint32_t *__restrict__ nan_seen, float *__restrict__ strips,
+                                                          uint32_t strips_w) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t x0 = blockIdx.x * 256u + 4u * lane;
     const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
     if (y0 >= h) return;  // the whole wave lies below the image
-    hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane, nan_seen);
+    hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane, nan_seen, strips, strips_w);
 }
 
 template <bool COPY>
@@ -403,23 +418,30 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
 // launch for levels >= 7 (measured cross-over: 2560x1440 14.6 us against 15.4 us streamed, 3840x2160
 // 25.0 us against 22.9 us); 1 = always the latter; 2 = tiles on the depth image with the top levels
 // inside the same launch; 3 = always the streaming pass.
+// Does launch_hiz(mode) run the streaming pass on a w x h image, i.e. does it write `strips`
+// (hiz_strip_extent(w) x hiz_strip_extent(h) floats: the largest depth of every 64 x 8 strip of the image)?
+bool hiz_writes_strips(uint32_t w, uint32_t h, int mode) {
+    return w >= 32 && h >= 32 && (mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels));
+}
+
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, int mode, hipStream_t st) {
+                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st) {
     if (w < 4 || h < 4) {
         hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, levels,
                            0u, nan_seen);
         return hipGetLastError();
     }
     // level 3 must itself be at least 4x4, the tiled kernel's own precondition
-    const bool stream = mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels);
-    if (!stream || w < 32 || h < 32)
+    if (!hiz_writes_strips(w, h, mode))
         return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, nan_seen, st);
     constexpr uint32_t base = 3;  // the last level the streaming pass writes
     const dim3 grid((w + 255u) / 256u, (h + 4u * kRowsPerWave - 1u) / (4u * kRowsPerWave));
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
                      (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u;
-    if (vec) hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen);
-    else hipLaunchKernelGGL((hiz_rows_kernel<false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen);
+    if (vec) hipLaunchKernelGGL((hiz_rows_kernel<true>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen,
+                                strips, (w + 63u) / 64u);
+    else hipLaunchKernelGGL((hiz_rows_kernel<false>), grid, dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, nan_seen, strips,
+                            (w + 63u) / 64u);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || levels <= base + 1u) return e;
     // the tiled kernel with the last level written above as its source: the table pointer and the level count shift

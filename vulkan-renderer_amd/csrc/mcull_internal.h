@@ -30,6 +30,10 @@ struct ViewConst {
     // this pyramid slot was built from held a NaN
     const uint32_t *level_table;
     const float *pyramid;
+    // largest depth of every 64 x 8 strip of the depth image the pyramid was built from (strips_w per row), or
+    // nullptr: lets the occlusion test skip the texel read of a pair that is in front of everything there
+    const float *strips;
+    uint32_t strips_w;
     // the guarded-exact predicates: force_exact != 0 sends every pair through the IEEE expressions (measurements,
     // tests); slow_pairs != nullptr counts the pairs that had to leave the fast forms
     uint32_t force_exact;
@@ -115,8 +119,11 @@ size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs
 // launch sets to 1 when the depth image holds a NaN and never clears (`nan_seen` points at it).
 constexpr size_t kHizCounterBytes = 2048;
 constexpr uint32_t kHizTableWords = 64, kHizNanWord = 48;
+// `strips` (optional): (w + 63) / 64 x (h + 7) / 8 floats, the largest depth of every 64 x 8 strip of the image, row by
+// row; written only when hiz_writes_strips says so (the streaming scheme, large images).
+bool hiz_writes_strips(uint32_t w, uint32_t h, int mode);
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
-                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, int mode, hipStream_t st);
+                      const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st);
 
 
 }  // namespace mcull
