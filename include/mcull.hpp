@@ -180,7 +180,23 @@ public:
                                            params.empty() ? nullptr : params.data(), r.data()));
         return r;
     }
+    // the same cull for a caller that must not allocate (HIP graph capture, a loop that may never reach hipMalloc):
+    // list, commands and total in `params` are the caller's; limits MCULL_STATIC_MAX_GROUPS / _INSTANCES
+    mcull_cull_result cullStatic(const Globals &globals, const mcull_cull_params &params) {
+        mcull_cull_result r{};
+        MCULL_CHECK(ctx_, mcull_cull_static(ctx_, &globals, &params, &r));
+        return r;
+    }
     void selectResult(uint32_t view) { MCULL_CHECK(ctx_, mcull_select_result(ctx_, view)); }
+    // what the instance level of the last cull removed: {marked, tested}, in instances or (scenes with ranges) groups
+    struct PrecullStats { uint64_t marked, tested; bool perGroup; };
+    PrecullStats precullStats() {
+        PrecullStats s{0, 0, false};
+        int per_group = 0;
+        MCULL_CHECK(ctx_, mcull_precull_stats(ctx_, &s.marked, &s.tested, &per_group));
+        s.perGroup = per_group != 0;
+        return s;
+    }
     uint64_t visibleCount() {
         uint64_t n = 0;
         MCULL_CHECK(ctx_, mcull_download_count(ctx_, &n));

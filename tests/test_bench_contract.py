@@ -10,8 +10,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[12]_bench_*.json")))
 LINES = [p for p in LINES if not p.endswith("_summary.json")]
+HEADLINE = os.path.join(ROOT, "profiles", "r02_bench_config4.json")
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -23,7 +24,7 @@ def test_committed_bench_line_has_the_contract_fields(path):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j, key
-    assert j["vs_baseline"] is None and j["higher_is_better"] is True and j["scaling"] == "weak" and j["data"] == "synthetic"
+    assert j["vs_baseline"] is None and j["higher_is_better"] is True and j["scaling"] in ("weak", "strong") and j["data"] == "synthetic"
     assert isinstance(j["config"].get("workload"), str) and "model" not in j["config"]
     r = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -33,6 +34,10 @@ def test_committed_bench_line_has_the_contract_fields(path):
     assert 0.0 < r["frac"] < 1.0
     if r["traffic"] is not None:  # measured bytes within a factor of the algorithmic ones
         assert 0.5 < r["traffic"] / r["algorithmic_bytes"] < 1.5
+    if "all_bounds" in r:  # lines of a cull with the instance pre-cull: the figure with every bound counted as read
+        a = r["all_bounds"]
+        assert a["algorithmic_bytes"] - a["bounds_bytes_not_touched"] <= r["algorithmic_bytes"] + 4 * j["config"].get("pairs_reaching_hiz", 0)
+        assert abs(a["frac"] - a["achieved"] / r["peak"]) < 1e-3
     c = j["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
@@ -43,12 +48,35 @@ def test_committed_bench_line_has_the_contract_fields(path):
 def test_headline_line_is_the_metric_baseline_names():
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
-    with open(os.path.join(ROOT, "profiles", "r01_bench_config4.json")) as f:
+    with open(HEADLINE) as f:
         j = json.load(f)
     assert j["n_gpus"] == 1 and j["dtype"] == "f32"
     assert "meshlet-instances" in j["metric"] and "meshlet-instances" in base["metric"]
     assert j["config"]["meshlet_instances_per_gpu"] == 100_000_000
     assert j["roofline"]["frac"] >= 0.6  # the target the measurement plan sets for the combined cull + compact step
+
+
+def test_headline_traffic_agrees_with_the_algorithmic_bytes():
+    """The counter passes of the headline command (profiles/r02_bench_config4_summary.json: FETCH_SIZE doubled,
+    WRITE_SIZE as is, per kernel and launch) against the bytes the line prices the step at: the counters are
+    exact on this chip (a calibration kernel reads back its own request count), so the ratio has to be tight."""
+    with open(HEADLINE) as f:
+        r = json.load(f)["roofline"]
+    with open(os.path.join(ROOT, "profiles", "r02_bench_config4_summary.json")) as f:
+        summ = json.load(f)
+    step = ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel", "emit_commands_kernel")
+    traffic = sum(row.get("fetch_bytes_corrected", 0) + row.get("write_bytes_corrected", 0)
+                  for name, row in summ.items() if any(k in name for k in step))
+    assert 0.95 <= traffic / r["algorithmic_bytes"] <= 1.25, traffic / r["algorithmic_bytes"]
+    if r["traffic"] is not None:  # the line quotes the summary that was committed when it ran: counter passes repeat within a per cent
+        assert abs(r["traffic"] - traffic) / traffic < 0.01
+    trace = {}
+    with open(os.path.join(ROOT, "profiles", "r02_bench_config4_kernel_stats.csv")) as f:
+        for line in f.read().splitlines()[1:]:
+            cells = line.rsplit(",", 5)
+            trace[cells[0]] = float(cells[2])
+    per_step = sum(v for k, v in trace.items() if any(s in k for s in step))
+    assert abs(per_step / 1e3 - r["kernel_ms"]) / r["kernel_ms"] < 0.05, "the trace's kernel durations add up to the step the line reports"
 
 
 def test_bench_command_line_keeps_the_driver_flags():
