@@ -69,7 +69,7 @@ def run(mc, O, pctx, g, view, cone, sphere, t, off, cnt, tests, hiz_view=0):
     return marked, hidden, ref
 
 
-@pytest.mark.parametrize("size", [(1000, 562), (640, 360), (2047, 1153), (1001, 563)])
+@pytest.mark.parametrize("size", [(1000, 562), (640, 360), (2047, 1153), (1001, 563), (1029, 517)])
 def test_instances_behind_discs(mc, O, H, pctx, size):
     w, h = size
     cone, sphere, t, off, cnt = scene(H, 1500, 40, seed=100 + w)
@@ -209,3 +209,79 @@ def test_negative_radii_and_hostile_transforms(mc, O, H, pctx):
             for tests in (4, 7):
                 marked, hidden, _ = run(mc, O, pctx, g, O.View(g, pyr, w, h), cone, sphere, t, off, cnt, tests)
                 assert marked > 0
+
+
+@pytest.mark.parametrize("depth_kind", ["discs", "checker", "far"])
+def test_several_views_with_the_instance_level(mc, O, H, pctx, depth_kind):
+    """mcull_cull_views classifies every instance per view first (dropped / needs no frustum test / needs no occlusion
+    test) and the pass over the bounds leaves those tests out: identical outputs for every view, whatever mix of
+    verdicts the views produce ("far": a depth image nothing is ever behind, every instance in the open)."""
+    import torch
+
+    w, h, nv = 1024, 640, 6
+    cone, sphere, t, off, cnt = scene(H, 900, 48, seed=31, extent=22.0)
+    pctx.upload_bounds_soa(cone, sphere)
+    pctx.upload_transforms(t)
+    pctx.set_instance_ranges(off, cnt)
+    views, params, refs = [], [], []
+    for v in range(nv):
+        if depth_kind == "discs":
+            depth = H.synthetic_depth(w, h, n_discs=16, seed=70 + v)
+            depth[depth > 0] += np.float32(0.12)
+        elif depth_kind == "checker":
+            depth = checkerboard(w, h, [8, 64, 200, 16, 300, 128][v])
+        else:
+            depth = np.full((h, w), 0.04, dtype="<f4")
+        ang = 2 * np.pi * v / nv
+        g = H.create_globals(eye=(38 * np.cos(ang), 38 * np.sin(ang), 8.0 + 5 * v), fov_deg=25.0 + 8 * v, width=w, height=h,
+                             flip_y=bool(v & 1))
+        pctx.hiz_build(depth, view=v)
+        tests = [7, 7, 5, 6, 3, 4][v]
+        views.append(g)
+        params.append(dict(tests=tests, hiz_view=v, write_mask=True))
+        refs.append(O.cull_scene(O.View(g, O.hiz_build(depth), w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt),
+                                 tests=tests))
+    pctx.cull_views(views, params)
+    for v in range(nv):
+        pctx.select_result(v)
+        compare(mc, pctx, refs[v], len(t))
+    packed = np.concatenate([np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1) for g in views])
+    g_dev = torch.from_numpy(packed.view("u1").reshape(-1).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    pctx.cull_views(nv, params, device_globals_ptr=g_dev.data_ptr(), meshlet_count=0)
+    for v in range(nv):
+        pctx.select_result(v)
+        compare(mc, pctx, refs[v], len(t))
+    off_params = [dict(p, precull=False) for p in params]
+    pctx.cull_views(views, off_params)
+    for v in range(nv):
+        pctx.select_result(v)
+        compare(mc, pctx, refs[v], len(t))
+
+
+@pytest.mark.parametrize("size", [(1280, 720), (1029, 517), (1543, 1031)])
+def test_large_instances(mc, O, H, pctx, size):
+    """Instances that cover hundreds of pixels: their screen rectangles are taller than eight 64 x 8 strips, so the
+    "nothing of it is occluded" verdict comes from the 64 x 64 block maxima (1029 x 517: the last columns and rows
+    of the image lie outside what the blocks cover, instances there get no verdict).  Both kinds of depth image:
+    discs (some instances in the open, some straddling, some hidden) and a far plane (all in the open)."""
+    w, h = size
+    cone, sphere, t, off, cnt = scene(H, 500, 64, seed=200 + w, radius=(0.02, 0.2), scales=(2.0, 9.0), extent=24.0)
+    pctx.upload_bounds_soa(cone, sphere)
+    pctx.upload_transforms(t)
+    pctx.set_instance_ranges(off, cnt)
+    for kind in ("discs", "far", "wall"):
+        if kind == "discs":
+            depth = H.synthetic_depth(w, h, n_discs=10, seed=h)
+            depth[depth > 0] += np.float32(0.1)
+        elif kind == "far":
+            depth = np.full((h, w), 0.03, dtype="<f4")
+        else:
+            depth = np.full((h, w), 0.02, dtype="<f4")
+            depth[:, w // 2:] = 0.6
+        pctx.hiz_build(depth, view=3)
+        pyr = O.hiz_build(depth)
+        for flip in (False, True):
+            g = H.create_globals(eye=(45.0, 40.0, 33.0), width=w, height=h, flip_y=flip, fov_deg=50.0)
+            for tests in (7, 4, 5):
+                run(mc, O, pctx, g, O.View(g, pyr, w, h), cone, sphere, t, off, cnt, tests, hiz_view=3)

@@ -117,7 +117,8 @@ template <bool VEC, bool SINGLE_PASS, bool COPY>
 __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
                                                           uint32_t levels, uint32_t *__restrict__ counter,
-                                                          uint32_t *__restrict__ nan_seen) {
+                                                          uint32_t *__restrict__ nan_seen, float *__restrict__ strips,
+                                                          uint32_t strips_w, uint32_t strips_h) {
     __shared__ float s2[16][17];
     const uint32_t t = threadIdx.x, tx = t & 15u, ty = t >> 4;
     const uint32_t x0 = blockIdx.x * kTile + 4 * tx, y0 = blockIdx.y * kTile + 4 * ty;
@@ -187,7 +188,25 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     // ---- levels 3..6: the 16x16 level-2 values are in LDS; from here on 64 lanes suffice, so waves
     // 1-3 leave (their wave slots go to the next workgroup's loads) and wave 0 reduces level 3 from
     // LDS and levels 4-6 with lane shuffles, without any further workgroup barrier.
-    if (t >= 64u) return;
+    if (t >= 64u) {
+        // Second launch of the streaming scheme (the source is level 3: the tile is 512 x 512 pixels of the image): the
+        // strip maxima the first launch wrote are reduced once more, eight strips to one 64 x 64 block of the image,
+        // stored behind the strips (strips_w per row of blocks), so that a large screen rectangle is covered by a few
+        // blocks.  The tile's 8 x 8 blocks are one per lane of the last wave, which has nothing else left to do; the
+        // first wave's ladder and tickets below do not wait for it.
+        if (!COPY && strips && t >= 192u) {
+            const uint32_t l = t - 192u;
+            const uint32_t sc = blockIdx.x * 8u + (l & 7u), br = blockIdx.y * 8u + (l >> 3);
+            if (sc < strips_w && br * 8u < strips_h) {
+                float mx = -__builtin_inff();
+#pragma unroll
+                for (uint32_t r = 0; r < 8; r++)
+                    mx = fmaxf(mx, strips[(size_t)min(br * 8u + r, strips_h - 1u) * strips_w + sc]);
+                strips[(size_t)strips_w * strips_h + (size_t)br * strips_w + sc] = mx;
+            }
+        }
+        return;
+    }
     if (levels > 3) {
         const uint32_t ox2 = (blockIdx.x * kTile) >> 2, oy2 = (blockIdx.y * kTile) >> 2;  // tile origin in level 2
         const uint32_t x = t & 7u, y = t >> 3;
@@ -385,25 +404,25 @@ __global__ __launch_bounds__(kBlock) void hiz_rows_kernel(const float *__restric
 template <bool COPY>
 static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
                                const uint32_t *level_table, uint32_t *counter, bool single_pass, uint32_t *nan_seen,
-                               hipStream_t st) {
+                               float *strips, uint32_t strips_w, uint32_t strips_h, hipStream_t st) {
     const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(src) & 15u) == 0u &&
                      (!COPY || (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u);
     if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
         if (vec)
             hipLaunchKernelGGL((hiz_tile_kernel<true, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                               level_table, levels, counter, nan_seen);
+                               level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
         else
             hipLaunchKernelGGL((hiz_tile_kernel<false, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                               level_table, levels, counter, nan_seen);
+                               level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
         return hipGetLastError();
     }
     if (vec)
         hipLaunchKernelGGL((hiz_tile_kernel<true, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                           level_table, levels, counter, nan_seen);
+                           level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
     else
         hipLaunchKernelGGL((hiz_tile_kernel<false, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
-                           level_table, levels, counter, nan_seen);
+                           level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (levels > 7) {
@@ -418,11 +437,15 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
 // launch for levels >= 7 (measured cross-over: 2560x1440 14.6 us against 15.4 us streamed, 3840x2160
 // 25.0 us against 22.9 us); 1 = always the latter; 2 = tiles on the depth image with the top levels
 // inside the same launch; 3 = always the streaming pass.
-// Does launch_hiz(mode) run the streaming pass on a w x h image, i.e. does it write `strips`
-// (hiz_strip_extent(w) x hiz_strip_extent(h) floats: the largest depth of every 64 x 8 strip of the image)?
+// Does launch_hiz(mode) run the streaming pass on a w x h image, i.e. does it write `strips`: the largest depth of
+// every 64 x 8 strip of the image ((w + 63) / 64 per row, (h + 7) / 8 rows), followed by the largest depth of every
+// 64 x 64 block ((w + 63) / 64 per row, (h + 63) / 64 rows; written for the blocks inside the cover of the second
+// launch's tiles, hiz_block_cover) - hiz_strip_floats(w, h) floats in all?
 bool hiz_writes_strips(uint32_t w, uint32_t h, int mode) {
     return w >= 32 && h >= 32 && (mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels));
 }
+
+size_t hiz_strip_floats(uint32_t w, uint32_t h) { return (size_t)((w + 63u) / 64u) * ((h + 7u) / 8u + (h + 63u) / 64u); }
 
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
                       const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st) {
@@ -433,7 +456,7 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
     }
     // level 3 must itself be at least 4x4, the tiled kernel's own precondition
     if (!hiz_writes_strips(w, h, mode))
-        return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, nan_seen, st);
+        return launch_tiles<true>(depth, w, h, pyramid, levels, level_table, counter, mode == 2, nan_seen, nullptr, 0u, 0u, st);
     constexpr uint32_t base = 3;  // the last level the streaming pass writes
     const dim3 grid((w + 255u) / 256u, (h + 4u * kRowsPerWave - 1u) / (4u * kRowsPerWave));
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(depth) & 15u) == 0u &&
@@ -448,7 +471,7 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
     size_t off = 0;
     for (uint32_t i = 0; i < base; i++) off += (size_t)max(1u, w >> i) * max(1u, h >> i);
     return launch_tiles<false>(pyramid + off, w >> base, h >> base, pyramid, levels - base, level_table + base, counter, true, nan_seen,
-                               st);
+                               strips, (w + 63u) / 64u, (h + 7u) / 8u, st);
 }
 
 }  // namespace mcull

@@ -118,6 +118,11 @@ struct mcull_ctx {
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
     bool hiz_strips = true;  // MCULL_HIZ_STRIPS=0: no strip maxima, every occlusion test reads its texel (measurements)
+    bool precull_flags = true;  // MCULL_PRECULL_FLAGS=0: the instance level only drops instances, it narrows no tests (measurements)
+    DevBuf view_flags;          // multi-view culls: one byte per instance and view slot (classify_views_kernel)
+    bool views_probe_pending = false;  // a multi-view pre-pass whose yield has not been looked at yet (kept_host[1])
+    uint64_t views_probe_units = 0;
+    uint32_t views_cooldown = 0;
     // Scenes below this many 64-meshlet groups are launch-bound: the instance pre-cull's extra launch and memset
     // (8 - 15 us) cost more than the groups it removes (the mask pass does about 4000 groups per microsecond; the
     // reference's scene, 6000 groups: 76 us per two-phase frame without it, 100 us with it).
@@ -337,6 +342,7 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     // The pyramid scheme is chosen by image size (launch_hiz); these switches force one of the schemes
     // for evaluation and tests (results are identical)
     if (const char *hs = std::getenv("MCULL_HIZ_STRIPS")) c->hiz_strips = hs[0] != '0';
+    if (const char *pf = std::getenv("MCULL_PRECULL_FLAGS")) c->precull_flags = pf[0] != '0';
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
     const char *fs = std::getenv("MCULL_FORCE_STREAMING");
@@ -365,7 +371,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->depth, &c->view_dev, &c->raster_scratch,
+                      &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->view_flags, &c->depth, &c->view_dev, &c->raster_scratch,
                       &c->range_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
@@ -650,7 +656,7 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
         src = (const float *)c->depth_staging.p;
     }
     s.has_strips = c->hiz_strips && mcull::hiz_writes_strips(width, height, c->hiz_mode);
-    if (s.has_strips && (rc = ensure(c, s.strips, (size_t)((width + 63u) / 64u) * ((height + 7u) / 8u) * 4))) return rc;
+    if (s.has_strips && (rc = ensure(c, s.strips, mcull::hiz_strip_floats(width, height) * 4))) return rc;
     s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
@@ -788,7 +794,21 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     plan->streaming = c->force_streaming || c->n_meshlets * 32ull > (64ull << 20);
     // the strip maxima save memory traffic and cost arithmetic: for the passes that are bound by memory only
     // (1 M instances of one cache-resident mesh: 12.2 ms without, 12.9 ms with them)
-    if (!plan->streaming) v.strips = nullptr;
+    v.strips_per_pair = (plan->streaming && v.strips) ? 1u : 0u;
+    return MCULL_OK;
+}
+
+// The enclosing spheres of the meshlet ranges (one per instance, or one for the uniform case), recomputed after the
+// bounds, the ranges or the uniform meshlet count changed.
+int ensure_range_spheres(mcull_ctx *c, const mcull::SceneDev &s, uint32_t uniform_count) {
+    const bool ranged = c->have_ranges;
+    if (c->spheres_valid && c->spheres_ranged == ranged && (ranged || c->spheres_uniform_count == uniform_count)) return MCULL_OK;
+    const uint32_t n_ranges = ranged ? (uint32_t)c->n_instances : 1u;
+    if (int rc = ensure(c, c->range_spheres, mcull::range_sphere_bytes(n_ranges))) return rc;
+    HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, uniform_count, (float4 *)c->range_spheres.p, c->stream));
+    c->spheres_valid = true;
+    c->spheres_ranged = ranged;
+    c->spheres_uniform_count = uniform_count;
     return MCULL_OK;
 }
 
@@ -848,15 +868,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
         if (precull) {
             // instance pre-cull: its range spheres (recomputed after the bounds or ranges changed) and its output bytes
             const bool ranged = c->have_ranges;
-            if (!c->spheres_valid || c->spheres_ranged != ranged || (!ranged && c->spheres_uniform_count != plan->uniform_count)) {
-                const uint32_t n_ranges = ranged ? (uint32_t)c->n_instances : 1u;
-                if ((rc = ensure(c, c->range_spheres, mcull::range_sphere_bytes(n_ranges)))) return rc;
-                HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, plan->uniform_count,
-                                                      (float4 *)c->range_spheres.p, c->stream));
-                c->spheres_valid = true;
-                c->spheres_ranged = ranged;
-                c->spheres_uniform_count = plan->uniform_count;
-            }
+            if ((rc = ensure_range_spheres(c, s, plan->uniform_count))) return rc;
             plan->precull_units = ranged ? s.n_groups : c->n_instances;
             if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
             plan->work = (uint32_t *)o.work.p;
@@ -945,6 +957,11 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
                                               (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
+        // The pre-pass also tells the mask pass which instances need no frustum / no occlusion test (two bits in the
+        // work list's entries) where that arithmetic is what the pass waits for: cache-resident bounds (1 M instances of
+        // one mesh: mask pass 12.2 -> 11.3 ms).  A pass over streamed bounds is bound by its bytes and keeps its constant
+        // tests (100 M pairs with the occlusion test: 0.278 ms without the flags, 0.285 ms with them).
+        const bool hand_on = pl.work && c->precull_flags && c->n_instances < (1ull << 30) && !pl.streaming;
         if (pl.work) {
             // the mask pass will cover the work list's groups only: every other ballot is zero from here
             HIPCHK(c, hipMemsetAsync(pl.work, 0, 4, c->stream));
@@ -953,10 +970,10 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
             if (!inline_zero) HIPCHK(c, hipMemsetAsync(o.mask.p, 0, pl.s.n_groups * 8, c->stream));
             HIPCHK(c, mcull::launch_instance_precull(pl.s, (const float4 *)c->range_spheres.p, c->have_ranges,
                                                      c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl.v, view_dev,
-                                                     pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, c->stream));
+                                                     pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, hand_on, c->stream));
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
-                                          c->stream, view_dev, pl.work, c->precull_adaptive ? c->kept_dev : nullptr));
+                                          c->stream, view_dev, pl.work, c->precull_adaptive ? c->kept_dev : nullptr, hand_on));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
@@ -1094,7 +1111,45 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
             masks[i] = (uint64_t *)c->out[i].mask.p;
             counts[i] = (uint32_t *)c->out[i].tile_counts.p;
         }
-        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev));
+        // instance level of the multi-view pass: one byte per instance and view (dropped / no frustum test / no occlusion
+        // test); backs off like the single-view one when fewer than a tenth of the bytes say anything
+        bool classify = c->precull_flags && pl[0].s.n_groups >= c->precull_min_groups;
+        bool any_test = false;
+        for (uint32_t i = 0; i < n_views; i++) {
+            any_test |= (pl[i].p.tests & (MCULL_TEST_FRUSTUM | MCULL_TEST_HIZ)) != 0;
+            if (pl[i].p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) classify = false;
+        }
+        classify = classify && any_test;
+        if (classify && c->precull_adaptive) {
+            if (c->views_probe_pending) {
+                const uint32_t useful = c->kept_host[1];
+                if (useful != 0xffffffffu) {
+                    c->views_probe_pending = false;
+                    if ((uint64_t)useful * 10 < c->views_probe_units) c->views_cooldown = kPrecullCooldown;
+                }
+            }
+            if (c->views_cooldown) {
+                c->views_cooldown--;
+                classify = false;
+            }
+        }
+        uint32_t *useful_dev = nullptr, *useful_report = nullptr;
+        if (classify) {
+            if (int rc = ensure_range_spheres(c, pl[0].s, pl[0].uniform_count)) return rc;
+            if (int rc = ensure(c, c->view_flags, (size_t)c->n_instances * MCULL_MAX_VIEWS)) return rc;
+            useful_dev = (uint32_t *)c->out[0].total.p + 48;  // a spare word of the context-owned count buffer
+            HIPCHK(c, hipMemsetAsync(useful_dev, 0, 4, c->stream));
+            HIPCHK(c, mcull::launch_classify_views(pl[0].s, (const float4 *)c->range_spheres.p, c->have_ranges, n_views, vc, view_dev,
+                                                   (uint8_t *)c->view_flags.p, useful_dev, c->stream));
+            if (c->precull_adaptive && !c->views_probe_pending) {
+                c->kept_host[1] = 0xffffffffu;  // until this cull's mask pass reports
+                c->views_probe_pending = true;
+                c->views_probe_units = c->n_instances * n_views;
+                useful_report = c->kept_dev + 1;
+            }
+        }
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev,
+                                                classify ? (const uint8_t *)c->view_flags.p : nullptr, useful_dev, useful_report));
         for (uint32_t i = 0; i < n_views; i++)
             if (int rc = launch_ordered_tail(c, c->out[i], pl[i])) return rc;
     }

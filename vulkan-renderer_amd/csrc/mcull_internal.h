@@ -34,6 +34,7 @@ struct ViewConst {
     // nullptr: lets the occlusion test skip the texel read of a pair that is in front of everything there
     const float *strips;
     uint32_t strips_w;
+    uint32_t strips_per_pair;  // the per-pair occlusion test consults them too (memory-bound passes; the instance level always may)
     // the guarded-exact predicates: force_exact != 0 sends every pair through the IEEE expressions (measurements,
     // tests); slow_pairs != nullptr counts the pairs that had to leave the fast forms
     uint32_t force_exact;
@@ -64,13 +65,14 @@ bool needs_tile_offsets(uint64_t n_groups);  // the scatter pass wants one uint6
 // One pass over the scene for n_views views (ordered path only): views[i] -> masks[i], tile_counts[i].
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st,
-                                  const ViewConst *view_dev = nullptr);
+                                  const ViewConst *view_dev = nullptr, const uint8_t *view_flags = nullptr,
+                                  const uint32_t *useful = nullptr, uint32_t *useful_report = nullptr);
 // work: the instance pre-cull's work list (the pass then covers the listed groups only; the ballots of the others
 // must be zero already) or nullptr; kept_report: where the pass leaves the list's length (device pointer to
 // host-mapped memory) or nullptr
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr, const uint32_t *work = nullptr,
-                            uint32_t *kept_report = nullptr);
+                            uint32_t *kept_report = nullptr, bool flags = false);
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
 size_t range_sphere_bytes(uint32_t n_ranges);  // what launch_range_spheres writes: n float4 spheres, then n float largest radii
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
@@ -79,7 +81,13 @@ hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges
 // the pre-pass also zeroes the ballot words of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
-                                   hipStream_t st);
+                                   bool want_flags, hipStream_t st);
+// The pre-pass of a multi-view cull: one byte per instance and view slot (flags[instance * MCULL_MAX_VIEWS + view]:
+// bit 0 every meshlet rejected, bit 1 none rejected by the frustum test, bit 2 none by the occlusion test);
+// *useful (zeroed by the caller) receives the number of non-zero bytes.
+hipError_t launch_classify_views(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, uint32_t n_views,
+                                 const ViewConst *const *views, const ViewConst *view_dev, uint8_t *flags, uint32_t *useful,
+                                 hipStream_t st);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st);
@@ -119,9 +127,12 @@ size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs
 // launch sets to 1 when the depth image holds a NaN and never clears (`nan_seen` points at it).
 constexpr size_t kHizCounterBytes = 2048;
 constexpr uint32_t kHizTableWords = 64, kHizNanWord = 48;
-// `strips` (optional): (w + 63) / 64 x (h + 7) / 8 floats, the largest depth of every 64 x 8 strip of the image, row by
-// row; written only when hiz_writes_strips says so (the streaming scheme, large images).
+// `strips` (optional): hiz_strip_floats(w, h) floats - the largest depth of every 64 x 8 strip of the image, row by row
+// ((w + 63) / 64 per row), then of every 64 x 64 block (same row length; a block is written when its pixels lie inside
+// [0, 512 ceil((w >> 3) / 64)) x [0, 512 ceil((h >> 3) / 64)), the cover of the second launch's tiles); written only
+// when hiz_writes_strips says so (the streaming scheme, large images).
 bool hiz_writes_strips(uint32_t w, uint32_t h, int mode);
+size_t hiz_strip_floats(uint32_t w, uint32_t h);
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
                       const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st);
 
