@@ -657,13 +657,14 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
     for (int k = 0; k < 4; k++) {
         const float m0 = v.vp[k], m1 = v.vp[4 + k], m2 = v.vp[8 + k], m3 = v.vp[12 + k];
         c[k] = ((m0 * wx + m1 * wy) + m2 * wz) + m3;
-        const float len = sqrtf((m0 * m0 + m1 * m1) + m2 * m2) * 1.0001f;
+        const float len = __builtin_amdgcn_sqrtf((m0 * m0 + m1 * m1) + m2 * m2) * 1.0001f;  // 1 ulp, far inside the factor
         const float mag = ((fabsf(m0) * (fabsf(wx) + rho) + fabsf(m1) * (fabsf(wy) + rho)) + fabsf(m2) * (fabsf(wz) + rho)) + fabsf(m3);
         e[k] = len * rho * 1.0001f + mag * 1.52587890625e-5f;  // 2^-16: a thousand times the roundoff of both evaluations
     }
     const float cw_lo = c[3] - e[3], cw_hi = c[3] + e[3];
     if (!(cw_lo > 1.0e-12f && cw_hi < 1.0e18f)) return 0u;
-    const float r_lo = 1.0f / cw_hi, r_hi = 1.0f / cw_lo;  // 1/cw of any meshlet lies between them
+    // 1/cw of any meshlet lies between them (v_rcp_f32 is good to 1 ulp; the factors move the bounds outwards by 2^-20)
+    const float r_lo = __builtin_amdgcn_rcpf(cw_hi) * 0.99999905f, r_hi = __builtin_amdgcn_rcpf(cw_lo) * 1.00000095f;
     auto upper = [&](float x) { return x >= 0.0f ? x * r_hi : x * r_lo; };  // of x / cw
     auto lower = [&](float x) { return x >= 0.0f ? x * r_lo : x * r_hi; };
     const float slack = 2.44140625e-4f;  // 2^-12, relative: the roundings of the per-meshlet quotients and sums
@@ -708,11 +709,12 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
             const float nz_lb = (ql - fabsf(ql) * slack) - 1.0e-30f;
             float smax = -__builtin_inff();
             const float *row0 = table + (size_t)cy0 * v.strips_w + cx0;
-#pragma unroll
-            for (int32_t j = 0; j < 8; j++) {
-                const float *row = row0 + (size_t)min(j, ncy - 1) * v.strips_w;
-                smax = fmaxf(smax, fmaxf(row[0], row[min(1, ncx - 1)]));
-                if (ncx > 2) smax = fmaxf(smax, fmaxf(row[2], row[ncx - 1]));
+            // one row of cells per iteration, its (at most four) loads independent of each other: scattered 4-byte
+            // loads are what this kernel waits for, so none is issued for rows the rectangle does not have
+            const int32_t c1 = min(1, ncx - 1), c2 = min(2, ncx - 1), c3 = ncx - 1;
+            for (int32_t j = 0; j < ncy; j++) {
+                const float *row = row0 + (size_t)j * v.strips_w;
+                smax = fmaxf(fmaxf(smax, fmaxf(row[0], row[c1])), fmaxf(row[c2], row[c3]));
             }
             if (nz_lb >= smax - 0.05f) return kInstOpen;  // it cannot be hidden as well
         }
@@ -771,7 +773,8 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
     const float g12 = fabsf((c1.x * c2.x + c1.y * c2.y) + c1.z * c2.z);
     // the products and sums above carry a few units of roundoff relative to |col i||col j| <= the trace
     const float slack = ((g00 + g11) + g22) * 1.0e-6f;
-    const float F = sqrtf(fmaxf(fmaxf((g00 + g01) + g02, (g01 + g11) + g12), (g02 + g12) + g22) + slack) * 1.00001f;
+    // (the hardware square root, 1 ulp and denormals flushed: the factor and the absolute term cover both)
+    const float F = __builtin_amdgcn_sqrtf(fmaxf(fmaxf((g00 + g01) + g02, (g01 + g11) + g12), (g02 + g12) + g22) + slack) * 1.00001f + 1.0e-18f;
     const float ex = fabsf(sp.x) + R, ey = fabsf(sp.y) + R, ez = fabsf(sp.z) + R;
     const float ax = ((fabsf(c0.x) * ex + fabsf(c1.x) * ey) + fabsf(c2.x) * ez) + fabsf(c3.x);
     const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
@@ -782,7 +785,7 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
 #pragma unroll
         for (int p = 0; p < 5; p++) {
             const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2], d = v.frustum[p][3];
-            const float nlen = fmaxf(sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
+            const float nlen = fmaxf(__builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
             const float reach = nlen * F * R;
             const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
             const float base = ((nx * wx + ny * wy) + nz * wz) + d, margin = A * 1.52587890625e-5f;  // 2^-16
