@@ -440,8 +440,11 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         ev_comm = [torch.cuda.Event() for _ in range(2)]
         main = env.stream
 
+    host_s = [0.0, 0.0, 0]  # MCULL_BENCH_HOST_TIMES=1: host seconds spent enqueuing the culls / the gathers, steps
+
     def step(k, record=False, gather_lists=False):
         b = k & 1
+        t0 = time.perf_counter()
         if multi:
             main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
         ms = 0.0
@@ -470,6 +473,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                              precull=not args.no_precull, exact=args.exact)
                 if record:
                     ms += ctx.last_kernel_ms()
+        t1 = time.perf_counter()
         if multi:
             # per-rank counts -> every rank's list offset -> rebased per-instance commands, gathered
             # into one global draw-list description; runs on a side stream beside the next cull
@@ -481,11 +485,17 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 if gather_lists:
                     env.mdist.gather_visible_lists(lst, gathered[b][0])
                 ev_comm[b].record(comm)
+        host_s[0] += t1 - t0
+        host_s[1] += time.perf_counter() - t1
+        host_s[2] += 1
         if record:
             kernel_ms.append(ms)
 
     elapsed, dev_ms = env.timed(step, steps=steps, warmup=warmup)
     region_ms_per_step = dev_ms / steps
+    if os.environ.get("MCULL_BENCH_HOST_TIMES") and rank == 0:
+        print("host time per step: cull enqueue %.1f us, gather enqueue %.1f us (%d steps incl. warm-up)"
+              % (host_s[0] / host_s[2] * 1e6, host_s[1] / host_s[2] * 1e6, host_s[2]), file=sys.stderr)
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
     for k in range(min(steps, 10)):

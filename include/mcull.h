@@ -151,9 +151,15 @@ typedef struct mcull_task_payload {
  * on the way up, so a coarse texel then says nothing about the finer ones.  mcull_hiz_build notices a NaN in
  * the depth image; the occlusion half stays off for that view slot from then on (until the context is
  * destroyed), the results are unaffected.
- * MCULL_CULL_NO_INSTANCE_PRECULL switches the level off (measurements, parity tests); the library also drops
- * it by itself for a while after a cull in which it removed less than a tenth of the scene.
- * mcull_cull_views and mcull_cull_static have no such level.
+ * The same bounds also show when an instance lies inside all five planes, or in front of everything the
+ * pyramid holds under it (largest depth of the image region, from two small tables mcull_hiz_build leaves
+ * behind for images from 6 M texels on): the per-meshlet pass then leaves that test out for the instance's
+ * meshlets, where its arithmetic is what the pass waits for (scenes whose bounds stay cache-resident).
+ * mcull_cull_views has the level in the form of one verdict per instance and view (dropped / no frustum test /
+ * no occlusion test) in front of its single pass over the bounds.
+ * MCULL_CULL_NO_INSTANCE_PRECULL switches the level off (measurements, parity tests; for mcull_cull_views: when
+ * any view's params carry it); the library also drops it by itself for a while after a cull in which it
+ * removed, or had a verdict for, less than a tenth of the scene.  mcull_cull_static has no such level.
  * Bounds that were adopted in place (mcull_upload_bounds_soa with adopt) must be announced again with that
  * call after their contents change: the range spheres are derived from them. */
 #define MCULL_CULL_NO_INSTANCE_PRECULL 1u

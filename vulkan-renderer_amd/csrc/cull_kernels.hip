@@ -814,9 +814,7 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
 // ordered inside a workgroup's share and in arrival order between workgroups; the mask pass does not depend
 // on the order.  It never starts on a group that is not in the list: the ballots of those groups are zeroed
 // here (zero_mask; scenes with few groups per instance) or by a memset beforehand.
-// The multi-view pass has no such level: with one byte per view and group in front of it, it was slower
-// than without (8 views at 8192^2: 5.35 against 5.14 ms; that pass waits for its pyramid reads, not for
-// arithmetic).
+// The multi-view pass has its own form of this level (classify_views_kernel): no list, one byte per instance and view.
 __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *__restrict__ transforms,
                                                                   const float4 *__restrict__ spheres, uint32_t per_instance_sphere,
                                                                   const uint2 *__restrict__ ranges,
