@@ -285,3 +285,37 @@ def test_large_instances(mc, O, H, pctx, size):
             g = H.create_globals(eye=(45.0, 40.0, 33.0), width=w, height=h, flip_y=flip, fov_deg=50.0)
             for tests in (7, 4, 5):
                 run(mc, O, pctx, g, O.View(g, pyr, w, h), cone, sphere, t, off, cnt, tests, hiz_view=3)
+
+
+@pytest.mark.parametrize("switches", [{"MCULL_PRECULL_FLAGS": "0"}, {"MCULL_HIZ_STRIPS": "0", "MCULL_HIZ_STREAM": "1"},
+                                      {"MCULL_PRECULL_ADAPTIVE": "1"}], ids=["no-verdicts", "no-strips", "adaptive"])
+def test_evaluation_switches_change_nothing(mc, O, H, monkeypatch, switches):
+    """The switches that take parts of the instance level away (measurements) leave every output as it is."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_PRECULL_ADAPTIVE", "0")
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    w, h = 900, 520
+    cone, sphere, t, off, cnt = scene(H, 700, 40, seed=404, scales=(0.3, 4.0), extent=20.0)
+    depth = H.synthetic_depth(w, h, n_discs=12, seed=9)
+    depth[depth > 0] += np.float32(0.1)
+    pyr = O.hiz_build(depth)
+    with mc.Context(0) as c:
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        c.set_instance_ranges(off, cnt)
+        views, params, refs = [], [], []
+        for v in range(3):
+            c.hiz_build(depth, view=v)
+            g = H.create_globals(eye=(36.0 - 10 * v, 30.0, 24.0 + 6 * v), width=w, height=h, flip_y=bool(v & 1))
+            views.append(g)
+            params.append(dict(tests=[7, 5, 6][v], hiz_view=v, write_mask=True))
+            refs.append(O.cull_scene(O.View(g, pyr, w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=[7, 5, 6][v]))
+        for rep in range(3):  # repeated: the adaptive variant decides from the previous cull
+            for v in range(3):
+                c.cull(views[v], **params[v])
+                compare(mc, c, refs[v], len(t))
+            c.cull_views(views, params)
+            for v in range(3):
+                c.select_result(v)
+                compare(mc, c, refs[v], len(t))
