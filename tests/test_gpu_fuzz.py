@@ -15,23 +15,36 @@ pytestmark = pytest.mark.gpu
 _SCALE = int(os.environ.get("MCULL_FUZZ_SCALE", "1"))
 
 
+def _context_with(mc, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return mc.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 @pytest.fixture(scope="module")
 def contexts(mc):
-    plain = mc.Context(0)
-    os.environ["MCULL_FORCE_STREAMING"] = "1"
-    try:
-        streamed = mc.Context(0)
-    finally:
-        del os.environ["MCULL_FORCE_STREAMING"]
-    yield plain, streamed
-    plain.close()
-    streamed.close()
+    """Cache-resident kernels, streamed kernels, and the streaming pyramid scheme with its strip / block maxima; in all
+    three the instance level runs for scenes of any size and never backs off, so that the random scenes go through
+    it (the library's own threshold is the size from which it pays)."""
+    inst = dict(MCULL_PRECULL_MIN_GROUPS="1", MCULL_PRECULL_ADAPTIVE="0")
+    ctxs = (_context_with(mc, **inst), _context_with(mc, MCULL_FORCE_STREAMING="1", **inst),
+            _context_with(mc, MCULL_HIZ_STREAM="1", **inst), _context_with(mc, MCULL_FORCE_STREAMING="1", MCULL_HIZ_STREAM="1", **inst))
+    yield ctxs
+    for c in ctxs:
+        c.close()
 
 
 @pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_random_scene(mc, O, H, contexts, seed):
     rs = np.random.RandomState(1000 + seed)
-    ctx = contexts[seed & 1]
+    ctx = contexts[seed % len(contexts)]
     n_meshlets = int(rs.choice([1, 63, 64, 65, 200, 1000, 5000]))
     n_inst = int(rs.choice([1, 2, 7, 64, 257, 900]))
     cone, sphere = H.synthetic_bounds(n_meshlets, seed=seed)
@@ -259,7 +272,7 @@ def test_random_views_and_payloads(mc, O, H, contexts, seed):
     import torch
 
     rs = np.random.RandomState(11000 + seed)
-    ctx = contexts[seed & 1]
+    ctx = contexts[seed % len(contexts)]
     n_views = int(rs.randint(1, mc.MAX_VIEWS + 1))
     n_meshlets = int(rs.choice([1, 33, 64, 97, 500]))
     n_inst = int(rs.choice([1, 3, 70, 400]))
