@@ -385,3 +385,52 @@ def test_2_pow_32_visible_pairs_are_reported_not_wrapped(mc, H):
         assert c.download_count() == 300_000 * per
         cmds = c.download_commands(300_000).view(mc.CMD)
         assert int(cmds["taskCount"][0]) == per and int(cmds["firstTask"][-1]) == (300_000 - 1) * per
+
+
+@pytest.mark.parametrize("ranged", [False, True])
+def test_empty_tiles_are_left_to_the_command_pass(mc, O, H, ranged):
+    """Scenes with more than 1024 tiles whose instances span 32 groups or more: the scatter pass skips the tiles without
+    a visible pair and the command pass takes the list offsets of the instances that begin in them from the tile
+    offsets.  Whole lists, commands and the per-instance offsets (what an EXT frontend binds) against the oracle, with
+    empty instances, instances of ragged size and most of the scene out of view; then rebased as a second rank."""
+    rs = np.random.RandomState(11)
+    per = 2100
+    n = 8100
+    cone, sphere = H.synthetic_bounds(per if not ranged else 3000, seed=3)
+    t = H.synthetic_transforms(n, extent=60.0, seed=5)
+    if ranged:
+        cnt = rs.randint(1600, 3001, n).astype("<u4")
+        cnt[rs.rand(n) < 0.1] = 0
+        cnt[-1] = 0
+        off = np.minimum(rs.randint(0, 1400, n), 3000 - cnt).astype("<u4")
+        ranges = (off, cnt)
+    else:
+        ranges = None
+    w, h = 1280, 720
+    depth = H.synthetic_depth(w, h, n_discs=8, seed=2)
+    depth[depth > 0] += np.float32(0.1)
+    g = H.create_globals(eye=(70.0, 64.0, 50.0), centre=(40.0, 30.0, 20.0), fov_deg=28.0, width=w, height=h, flip_y=False,
+                         meshlet_count=per)
+    view = O.View(g, O.hiz_build(depth), w, h)
+    with mc.Context(0) as c:
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        c.set_instance_ranges(*(ranges if ranged else (None, None)))
+        c.hiz_build(depth, view=0)
+        for tests in (7, 1):
+            ref = O.cull_scene(view, t, cone_axis_w=cone, centre_radius=sphere, ranges=ranges, tests=tests, threads=8)
+            per_inst = ref.commands["taskCount"]
+            assert 0 < ref.total and (per_inst == 0).mean() > 0.5, "most instances have nothing visible: whole tiles are empty"
+            for precull in (True, False):
+                res = c.cull(g, tests=tests, write_mask=True, precull=precull)
+                assert c.download_count() == ref.total
+                assert c.download_list().tobytes() == ref.list.tobytes()
+                cmds = c.download_commands(n).view(mc.CMD).reshape(-1)
+                assert np.array_equal(cmds["taskCount"], per_inst) and np.array_equal(cmds["firstTask"], ref.commands["firstTask"])
+            # the same offsets again from the stored per-instance array: rebased behind a first rank of 1000 pairs
+            import torch
+
+            totals = torch.tensor([1000, ref.total], dtype=torch.int64, device="cuda:0")
+            c.rebase_commands(totals.data_ptr(), 1)
+            cmds = c.download_commands(n).view(mc.CMD).reshape(-1)
+            assert np.array_equal(cmds["firstTask"], (ref.commands["firstTask"].astype(np.uint64) + 1000).astype("<u4"))

@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
-    unsigned long long *__restrict__ total, uint32_t split) {
+    unsigned long long *__restrict__ total, uint32_t split, uint32_t skip_empty) {
     __shared__ uint64_t s_word[kBlock];
     __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
     __shared__ uint32_t s_wave[kWaves];
@@ -1283,6 +1283,12 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint32_t round_span = kTileGroups / split;  // groups whose entries this workgroup writes
     unsigned long long running;
     if (tile_offsets) {
+        // A tile without a visible pair has nothing to write; the list offsets of the instances that begin in it all
+        // equal the tile's, and the command pass takes them from the tile offsets itself (skip_empty; 1 M instances of
+        // one mesh, nine tiles in ten empty: 1.9 -> 1.5 ms for this pass).  The launcher asks for it when instances span
+        // many groups; with a hundred instances per tile the command pass's extra look-ups cost more (2.4 us for
+        // 781 250 instances) than the rare empty tile saves.
+        if (skip_empty && tile_counts[tile_idx] == 0u) return;
         running = tile_offsets[tile_idx];  // uniform: one scalar load
     } else {
         unsigned long long part = 0;
@@ -1386,7 +1392,8 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
     const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
     uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
-    uint32_t *__restrict__ tile_counts, uint32_t n_tiles) {
+    uint32_t *__restrict__ tile_counts, uint32_t n_tiles, const unsigned long long *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     // every consumer of the tile counters has finished (stream order): leave them zero for the next cull
     if (tile_counts && i < n_tiles) tile_counts[i] = 0;
@@ -1399,13 +1406,31 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
         task_count = inst_count[i];
         first_task = (uint32_t)base;
     } else {
-        const uint32_t tot = (uint32_t)*total;
+        const unsigned long long tot64 = *total;
+        const uint32_t tot = (uint32_t)tot64;
         const uint32_t mine = ranges ? ranges[i].y : uniform_count;
+        // The list offset of instance j.  With tile offsets (scan_tiles_kernel) the scatter pass skips the tiles
+        // without a visible pair; an instance that begins in one starts at that tile's offset, which is also
+        // stored into inst_first for later readers of the array (nobody reads that element in this launch: every
+        // reader takes this same branch for it).
+        auto first_of = [&](uint32_t j, bool store) {
+            if (tile_offsets) {
+                const uint32_t tile = (ranges ? group_base[j] : j * groups_per_instance) / kTileGroups;
+                if (tile < n_tiles) {
+                    const unsigned long long lo = tile_offsets[tile], hi = tile + 1u < n_tiles ? tile_offsets[tile + 1u] : tot64;
+                    if (hi == lo) {
+                        if (store) inst_first_w[j] = (uint32_t)lo;
+                        return (uint32_t)lo;
+                    }
+                }
+            }
+            return inst_first[j];
+        };
         // the next instance that owns meshlets: looked up (precomputed with the ranges: a scene with long runs of
         // empty instances would otherwise cost every thread a walk over the run), or simply the next one
         const uint32_t k = ranges ? next_nonempty[i] : i + 1u;
-        const uint32_t next_first = k < n_instances ? inst_first[k] : tot;
-        const uint32_t my_first = mine ? inst_first[i] : next_first;
+        const uint32_t next_first = k < n_instances ? first_of(k, false) : tot;
+        const uint32_t my_first = mine ? first_of(i, true) : next_first;
         task_count = next_first - my_first;
         first_task = my_first + (uint32_t)base;
     }
@@ -1638,10 +1663,15 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
 }
 
 // tile_offsets (one uint64 per tile) may be nullptr for scenes up to kScanMinTiles tiles
+// Does the scatter pass leave the tiles without a visible pair to the command pass (which must then be given the tile
+// offsets)?  Scenes with tile offsets whose instances span at least 32 groups each.
+bool skips_empty_tiles(const SceneDev &s) { return needs_tile_offsets(s.n_groups) && s.n_groups >= 32ull * s.n_instances; }
+
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st) {
     const uint32_t tiles = tile_count_for(s.n_groups);
+    const uint32_t skip_empty = skips_empty_tiles(s) ? 1u : 0u;
     // One workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
     // the tile scan) measured 118 / 152 us against 107 us for the 100 M-pair scene.  A scene with
     // fewer tiles than a quarter of the CUs is latency-bound instead, and four workgroups per tile, one
@@ -1659,24 +1689,27 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
     if (streaming)
         hipLaunchKernelGGL(compact_kernel<true>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
-                           (unsigned long long *)total, split);
+                           (unsigned long long *)total, split, skip_empty);
     else
         hipLaunchKernelGGL(compact_kernel<false>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
-                           (unsigned long long *)total, split);
+                           (unsigned long long *)total, split, skip_empty);
     return hipGetLastError();
 }
 
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
-                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st) {
-    const uint32_t n_tiles = tile_counts ? tile_count_for(s.n_groups) : 0;
+                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st,
+                                const uint64_t *tile_offsets, uint32_t *inst_first_w) {
+    if (!skips_empty_tiles(s)) tile_offsets = nullptr;  // the scatter pass has written every instance's offset itself
+    const uint32_t n_tiles = (tile_counts || tile_offsets) ? tile_count_for(s.n_groups) : 0;
     const uint32_t work = s.n_instances > n_tiles ? s.n_instances : n_tiles;
     if (work == 0) return hipSuccess;
     const uint32_t grid = (work + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, s.next_nonempty, uniform_count, s.n_instances,
                        inst_first, inst_count, total, rank_totals, rank, lay.stride, lay.offset, lay.form,
-                       (uint8_t *)commands, tile_counts, n_tiles);
+                       (uint8_t *)commands, tile_counts, n_tiles, (const unsigned long long *)tile_offsets, s.group_base,
+                       s.groups_per_instance, inst_first_w);
     return hipGetLastError();
 }
 

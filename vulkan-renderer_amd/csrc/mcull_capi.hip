@@ -749,6 +749,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
         if (c->ranged_max_end > c->n_meshlets) return fail(c, MCULL_E_INVALID, "an instance range exceeds the meshlet array");
         s.ranges = (const uint2 *)c->ranges.p;
         s.next_nonempty = (const uint32_t *)c->next_nonempty.p;
+        s.group_base = (const uint32_t *)c->group_base.p;
         s.group_rec = (const uint4 *)c->group_rec.p;
         s.groups_per_instance = 0;
         s.n_groups = c->ranged_groups;
@@ -895,7 +896,8 @@ int launch_ordered_tail(mcull_ctx *c, mcull_ctx::ViewOut &o, const CullPlan &pl)
                                     (uint32_t *)o.inst_first.p, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
     HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, (const uint32_t *)o.inst_first.p, nullptr,
                                           (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands,
-                                          (uint32_t *)o.tile_counts.p, c->stream));
+                                          (uint32_t *)o.tile_counts.p, c->stream,
+                                          pl.two_level ? (const uint64_t *)o.tile_offsets.p : nullptr, (uint32_t *)o.inst_first.p));
     o.counters_clean = true;
     return MCULL_OK;
 }
@@ -1047,7 +1049,8 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
         HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? tile_offsets : nullptr, pl.list, pl.capacity,
                                         inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, inst_first, nullptr, (const uint64_t *)pl.total, nullptr, 0,
-                                              pl.lay, pl.commands, tile_counts, c->stream));
+                                              pl.lay, pl.commands, tile_counts, c->stream, pl.two_level ? tile_offsets : nullptr,
+                                              inst_first));
     }
     if (result) {
         result->list = pl.list;

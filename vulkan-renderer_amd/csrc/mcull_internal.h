@@ -49,6 +49,7 @@ struct SceneDev {
     const float *xf_scale;        // length(model[0].xyz) per instance
     const uint2 *ranges;          // {meshletOffset, meshletCount} per instance, or nullptr
     const uint32_t *next_nonempty;  // with ranges: index of the next instance after i that owns meshlets (n_instances if none)
+    const uint32_t *group_base;     // with ranges: index of each instance's first 64-meshlet group (n_instances + 1 entries)
     const uint4 *group_rec;       // {instance, first meshlet, count, local group} per 64-meshlet group, or nullptr
     uint32_t n_instances;
     uint32_t groups_per_instance; // uniform case
@@ -93,7 +94,11 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
                           uint64_t *total, bool streaming, hipStream_t st);
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
-                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st);
+                                uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st,
+                                const uint64_t *tile_offsets = nullptr, uint32_t *inst_first_w = nullptr);
+// tile_offsets (with inst_first_w = the same array as inst_first): the scatter pass ran with tile offsets and skipped the
+// tiles without a visible pair; the command pass then takes the offsets of the instances that begin in such a tile from
+// the tile offsets and stores them into inst_first_w.
 hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
                               uint32_t *inst_count, uint64_t *total, uint64_t *mask, bool block_mode, hipStream_t st);
 hipError_t launch_rebase_gathered(void *gathered, uint32_t world, uint64_t rows, uint64_t *totals, uint64_t *bases, hipStream_t st);
