@@ -916,7 +916,17 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     uint32_t first_block = blockIdx.x;
     if (xcd_contiguous) first_block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (FLAGS && kept_report && blockIdx.x == 0 && threadIdx.x == 0) *kept_report = work[0];  // also when the list is empty
-    auto do_block = [&](const uint32_t block_g0) {
+    // The FLAGS form is the one for cache-resident scenes behind a work list, where whole scenes' worth of
+    // workgroups would start only to find the list shorter than the grid (1 M instances of one mesh, seven in eight
+    // dropped: 3 ms of a 11 ms pass; everything dropped: 3.3 ms for nothing).  A fixed number of workgroups walks
+    // the list with a stride instead.  (Streamed scenes keep one workgroup per 16 groups: a walking loop issues the
+    // next block's loads only after the last one's arithmetic, 4.9 against 6.4 TB/s.)  Every other form runs the
+    // loop's body exactly once.
+    uint32_t n_list = 0;
+    if constexpr (FLAGS) n_list = group_rec ? work[0] : work[0] * groups_per_instance;
+    for (uint32_t b = FLAGS ? blockIdx.x : first_block;; b += gridDim.x) {
+    if (FLAGS && (unsigned long long)b * kGroups >= n_list) break;
+    const uint32_t block_g0 = b * kGroups;
     // With a work list (instance_precull_kernel) the pass runs over the list's groups only: the grid is
     // sized for the whole scene and the workgroups beyond the list's end leave at once.
     // The list's length is device data.  So that no workgroup waits for it before it can ask for its records,
@@ -1025,20 +1035,8 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
             if (sum) atomicAdd(&tile_counts[tile], sum);
         }
     }
-    };
-    if constexpr (FLAGS) {
-        // The FLAGS form is the one for cache-resident scenes behind a work list, where whole scenes' worth of
-        // workgroups would start only to find the list shorter than the grid (1 M instances of one mesh, seven in eight
-        // dropped: 3 ms of a 11 ms pass; everything dropped: 3.3 ms for nothing).  A fixed number of workgroups walks
-        // the list with a stride instead.  (Streamed scenes keep one workgroup per 16 groups: a walking loop issues the
-        // next block's loads only after the last one's arithmetic, 4.9 against 6.4 TB/s.)
-        const uint32_t n_list = group_rec ? work[0] : work[0] * groups_per_instance;
-        for (uint32_t b = blockIdx.x; (unsigned long long)b * kGroups < n_list; b += gridDim.x) {
-            do_block(b * kGroups);
-            __syncthreads();  // the staging arrays are rewritten by the next block
-        }
-    } else {
-        do_block(first_block * kGroups);
+    if (!FLAGS) break;
+    __syncthreads();  // the staging arrays are rewritten by the next block
     }
 }
 
