@@ -754,9 +754,14 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
 // The same bound from the other side gives kInstInside: when (dot(n, W) + d) - reach - 2^-16 A > 0 for all five planes
 // and no radius of the range is negative, e_m >= 0 for every meshlet and the per-meshlet pass skips the frustum test.
 // want_more: also work out kInstInside / kInstOpen (the caller hands them on); otherwise only kInstCulled.
-__device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
-                                                      const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i,
-                                                      const ViewConst &v, bool want_more) {
+// what instance_classify needs of an instance, whatever the view: world-space sphere centre, the bound F on the
+// stretch of its matrix, the range's radius and largest meshlet radius, and the magnitudes the margins scale with
+struct InstanceGeom {
+    float wx, wy, wz, F, R, rmax_local, ax, ay, az;
+};
+
+__device__ __forceinline__ InstanceGeom instance_geometry(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+                                                          const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i) {
     const float4 *t = transforms + (size_t)i * 4;
     const float4 c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
     const float4 sp = spheres[per_instance_sphere ? i : 0u];
@@ -779,7 +784,11 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
     const float ax = ((fabsf(c0.x) * ex + fabsf(c1.x) * ey) + fabsf(c2.x) * ez) + fabsf(c3.x);
     const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
     const float az = ((fabsf(c0.z) * ex + fabsf(c1.z) * ey) + fabsf(c2.z) * ez) + fabsf(c3.z);
-    const float rmax_local = rmax[per_instance_sphere ? i : 0u];
+    return InstanceGeom{wx, wy, wz, F, R, rmax[per_instance_sphere ? i : 0u], ax, ay, az};
+}
+
+__device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, const ViewConst &v, bool want_more) {
+    const float wx = q.wx, wy = q.wy, wz = q.wz, F = q.F, R = q.R, rmax_local = q.rmax_local, ax = q.ax, ay = q.ay, az = q.az;
     bool outside = false, inside = rmax_local < 1.0e18f;  // +inf: a negative or non-finite radius in the range
     if (v.tests & MCULL_TEST_FRUSTUM) {
 #pragma unroll
@@ -807,6 +816,12 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
         flags |= o;
     }
     return flags;
+}
+
+__device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+                                                      const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i,
+                                                      const ViewConst &v, bool want_more) {
+    return classify_geometry(instance_geometry(transforms, spheres, rmax, per_instance_sphere, i), v, want_more);
 }
 
 // The pre-pass of a single-view cull: the WORK LIST of the mask pass (layout above; work[0] is zero on entry).
@@ -1053,27 +1068,35 @@ struct ViewSet {
     uint32_t n;
 };
 
-// The instance level of the multi-view pass: one thread per (instance, view slot), eight consecutive lanes = the
-// eight slots of one instance.  flags[instance][slot] = instance_classify's verdict for that view (zero for unused
-// slots); the mask pass stages an instance's eight bytes with its group record and drops or narrows the tests per
-// view.  (A byte that only says "outside the frustum" did not pay in front of a pass that waited for its texel
-// reads: 5.35 against 5.14 ms for 8 views at 8192^2.  With the occlusion verdicts and the tests it lets the pass
-// leave out, it does.)
+// The instance level of the multi-view pass: one thread per instance, which works out what does not depend on the view
+// once and then instance_classify's verdict for every view (the view's constants are wave-uniform: scalar loads).
+// flags[instance][slot] = the verdict for that view (zero for unused slots), eight bytes stored at once; the mask pass
+// stages them with the instance's group record and drops or narrows the tests per view.  (One thread per instance AND
+// view read the view constants per lane and repeated the instance's part eight times: 293 us for 781 250 instances
+// and 8 views.  A byte that only says "outside the frustum" did not pay in front of a pass that waited for its texel
+// reads: 5.35 against 5.14 ms for 8 views at 8192^2.  With the occlusion verdicts and the tests it lets the pass leave
+// out, it does.)
 __global__ __launch_bounds__(kBlock) void classify_views_kernel(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
                                                                 const float *__restrict__ rmax, uint32_t per_instance_sphere,
                                                                 uint32_t n_instances, ViewSet vs, const ViewConst *__restrict__ view_dev,
-                                                                uint8_t *__restrict__ flags, uint32_t *__restrict__ useful) {
+                                                                uint2 *__restrict__ flags, uint32_t *__restrict__ useful) {
     __shared__ uint32_t s_n[kWaves];
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t i = t / MCULL_MAX_VIEWS, slot = t % MCULL_MAX_VIEWS;
-    uint32_t f = 0;
-    if (i < n_instances && slot < vs.n) {
-        const ViewConst &v = view_dev ? view_dev[slot] : vs.v[slot];
-        f = instance_classify(transforms, spheres, rmax, per_instance_sphere, i, v, true);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t lo = 0, hi = 0, found = 0;
+    if (i < n_instances) {
+        const InstanceGeom q = instance_geometry(transforms, spheres, rmax, per_instance_sphere, i);
+        for (uint32_t slot = 0; slot < vs.n; slot++) {
+            const ViewConst &v = view_dev ? view_dev[slot] : vs.v[slot];
+            const uint32_t f = classify_geometry(q, v, true);
+            found += f != 0u;
+            if (slot < 4u) lo |= f << (8u * slot);
+            else hi |= f << (8u * (slot - 4u));
+        }
+        flags[i] = make_uint2(lo, hi);
     }
-    if (i < n_instances) flags[t] = (uint8_t)f;
-    const uint32_t n = (uint32_t)__popcll(__ballot(f != 0u));
-    if ((threadIdx.x & 63u) == 0u) s_n[threadIdx.x >> 6] = n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d, 64);
+    if ((threadIdx.x & 63u) == 0u) s_n[threadIdx.x >> 6] = found;
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t sum = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
@@ -1657,9 +1680,8 @@ hipError_t launch_classify_views(const SceneDev &s, const float4 *spheres, bool 
     vs.n = n_views;
     for (uint32_t i = 0; i < n_views; i++) vs.v[i] = *views[i];
     const float *rmax = reinterpret_cast<const float *>(spheres + (per_instance_sphere ? s.n_instances : 1u));
-    const uint64_t threads = (uint64_t)s.n_instances * MCULL_MAX_VIEWS;
-    hipLaunchKernelGGL(classify_views_kernel, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, s.transforms, spheres,
-                       rmax, per_instance_sphere ? 1u : 0u, s.n_instances, vs, view_dev, flags, useful);
+    hipLaunchKernelGGL(classify_views_kernel, dim3((s.n_instances + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.transforms, spheres,
+                       rmax, per_instance_sphere ? 1u : 0u, s.n_instances, vs, view_dev, reinterpret_cast<uint2 *>(flags), useful);
     return hipGetLastError();
 }
 
