@@ -1235,9 +1235,9 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
 // 13.9 G pairs have 851 000, 104 workgroups, of which the last reads 3.4 MB - against one workgroup walking
 // all of them with a running carry, two barriers per 8192, which took 0.50 ms there.  The scatter pass then
 // starts each tile with one load instead of summing the lower counters itself.
-__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
-                                                                unsigned long long *__restrict__ tile_offsets,
-                                                                unsigned long long *__restrict__ total) {
+__device__ __forceinline__ void scan_tiles_body(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
+                                                unsigned long long *__restrict__ tile_offsets,
+                                                unsigned long long *__restrict__ total) {
     constexpr int kScanWaves = kScanBlock / 64;
     __shared__ unsigned long long s_wave[kScanWaves];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1295,6 +1295,22 @@ __global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = carry + chunk;
 }
 
+__global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *__restrict__ tile_counts, uint32_t n_tiles,
+                                                                unsigned long long *__restrict__ tile_offsets,
+                                                                unsigned long long *__restrict__ total) {
+    scan_tiles_body(tile_counts, n_tiles, tile_offsets, total);
+}
+
+// The scatter and command passes of several views in one launch each (blockIdx.y = view): the buffers of every view.
+struct ViewTails {
+    ViewTail t[MCULL_MAX_VIEWS];
+};
+
+__global__ __launch_bounds__(kScanBlock) void scan_tiles_views_kernel(ViewTails tails, uint32_t n_tiles) {
+    const ViewTail &t = tails.t[blockIdx.y];
+    scan_tiles_body(t.tile_counts, n_tiles, (unsigned long long *)t.tile_offsets, (unsigned long long *)t.total);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ordered, pass 2: scatter.  `split` workgroups per 256-group tile (each redoes the tile's scan and
 // writes the entries of 256/split consecutive groups; the launcher uses 1 except for very small scenes).
@@ -1307,8 +1323,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_tiles_kernel(const uint32_t *
 // workgroups walks the tiles with a stride instead of one workgroup per tile, so that an empty tile costs a scalar load
 // and a branch, not a workgroup (1 M instances of one mesh, 851 000 tiles: 1.5 ms of this pass were workgroups that
 // started and left).
-template <bool NT, bool LOOP = false>
-__global__ __launch_bounds__(kBlock) void compact_kernel(
+template <bool NT, bool LOOP>
+__device__ __forceinline__ void compact_body(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
@@ -1435,12 +1451,31 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     }
 }
 
+template <bool NT, bool LOOP = false>
+__global__ __launch_bounds__(kBlock) void compact_kernel(
+    const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
+    const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
+    uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
+    unsigned long long *__restrict__ total, uint32_t split, uint32_t skip_empty) {
+    compact_body<NT, LOOP>(mask, tile_counts, tile_offsets, group_rec, groups_per_instance, n_groups, list, capacity, inst_first, total,
+                           split, skip_empty);
+}
+
+template <bool NT, bool LOOP = false>
+__global__ __launch_bounds__(kBlock) void compact_views_kernel(ViewTails tails, uint32_t with_offsets, const uint4 *__restrict__ group_rec,
+                                                               uint32_t groups_per_instance, uint32_t n_groups, uint32_t split,
+                                                               uint32_t skip_empty) {
+    const ViewTail &t = tails.t[blockIdx.y];
+    compact_body<NT, LOOP>(t.mask, t.tile_counts, with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_rec,
+                           groups_per_instance, n_groups, t.list, t.capacity, t.inst_first, (unsigned long long *)t.total, split, skip_empty);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-instance indirect commands (createIndirectBuffer, Engine.cpp:1466-1484, made dynamic).
 // ordered mode: inst_first[] holds the list offset of every instance that has meshlets;
 // taskCount_i = firstTask of the next non-empty instance (or the total) - firstTask_i.
 // atomic modes: inst_count[] holds visible_i, firstTask = base.
-__global__ __launch_bounds__(kBlock) void emit_commands_kernel(
+__device__ __forceinline__ void emit_commands_body(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ next_nonempty, uint32_t uniform_count, uint32_t n_instances,
     const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
@@ -1495,6 +1530,28 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
     } else {
         out[1] = first_task;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_commands_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ next_nonempty, uint32_t uniform_count, uint32_t n_instances,
+    const uint32_t *__restrict__ inst_first, const uint32_t *__restrict__ inst_count,
+    const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
+    uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
+    uint32_t *__restrict__ tile_counts, uint32_t n_tiles, const unsigned long long *__restrict__ tile_offsets,
+    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w) {
+    emit_commands_body(ranges, next_nonempty, uniform_count, n_instances, inst_first, inst_count, total, rank_totals, rank, stride, offset,
+                       form, commands, tile_counts, n_tiles, tile_offsets, group_base, groups_per_instance, inst_first_w);
+}
+
+// ordered mode only
+__global__ __launch_bounds__(kBlock) void emit_commands_views_kernel(ViewTails tails, uint32_t with_offsets, const uint2 *__restrict__ ranges,
+                                                                     const uint32_t *__restrict__ next_nonempty, uint32_t uniform_count,
+                                                                     uint32_t n_instances, uint32_t n_tiles,
+                                                                     const uint32_t *__restrict__ group_base, uint32_t groups_per_instance) {
+    const ViewTail &t = tails.t[blockIdx.y];
+    emit_commands_body(ranges, next_nonempty, uniform_count, n_instances, t.inst_first, nullptr, t.total, nullptr, 0u, t.lay.stride,
+                       t.lay.offset, t.lay.form, (uint8_t *)t.commands, t.tile_counts, n_tiles,
+                       with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_base, groups_per_instance, t.inst_first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1758,6 +1815,42 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
         hipLaunchKernelGGL(compact_kernel<false>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
                            (unsigned long long *)total, split, skip_empty);
+    return hipGetLastError();
+}
+
+// scatter + commands of n_views views of one scene: three launches in all (tile offsets, scatter, commands)
+hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint32_t n_views, const ViewTail *views, bool streaming,
+                                hipStream_t st) {
+    ViewTails tails;
+    std::memset(&tails, 0, sizeof tails);
+    for (uint32_t i = 0; i < n_views; i++) tails.t[i] = views[i];
+    const uint32_t tiles = tile_count_for(s.n_groups);
+    const bool offsets = needs_tile_offsets(s.n_groups), skip_empty = skips_empty_tiles(s);
+    const uint32_t split = tiles <= 64u ? 4u : tiles <= 128u ? 2u : 1u;
+    if (offsets) {
+        const uint32_t per_block = kScanBlock * kScanPerThread;
+        hipLaunchKernelGGL(scan_tiles_views_kernel, dim3((tiles + per_block - 1u) / per_block, n_views), dim3(kScanBlock), 0, st, tails, tiles);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t gx = skip_empty ? (tiles < 8192u ? tiles : 8192u) : tiles * split;
+#define MCULL_LAUNCH_COMPACT_VIEWS(NT_, LOOP_)                                                                                    \
+    hipLaunchKernelGGL((compact_views_kernel<NT_, LOOP_>), dim3(gx, n_views), dim3(kBlock), 0, st, tails, offsets ? 1u : 0u, s.group_rec, \
+                       s.groups_per_instance, (uint32_t)s.n_groups, skip_empty ? 1u : split, skip_empty ? 1u : 0u)
+    if (skip_empty) {
+        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, true);
+        else MCULL_LAUNCH_COMPACT_VIEWS(false, true);
+    } else {
+        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, false);
+        else MCULL_LAUNCH_COMPACT_VIEWS(false, false);
+    }
+#undef MCULL_LAUNCH_COMPACT_VIEWS
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t work = s.n_instances > tiles ? s.n_instances : tiles;
+    hipLaunchKernelGGL(emit_commands_views_kernel, dim3((work + kBlock - 1) / kBlock, n_views), dim3(kBlock), 0, st, tails,
+                       skip_empty ? 1u : 0u, s.ranges, s.next_nonempty, uniform_count, s.n_instances, tiles, s.group_base,
+                       s.groups_per_instance);
     return hipGetLastError();
 }
 

@@ -60,6 +60,19 @@ struct CmdLayout {
     uint32_t stride, offset, form;
 };
 
+// The buffers of one view's scatter + command passes (ordered compaction).
+struct ViewTail {
+    const uint64_t *mask;
+    uint32_t *tile_counts;
+    uint64_t *tile_offsets;  // used by scenes that need tile offsets (needs_tile_offsets)
+    mcull_visible *list;
+    uint64_t capacity;
+    uint32_t *inst_first;
+    uint64_t *total;
+    void *commands;
+    CmdLayout lay;
+};
+
 // ---- launchers (each returns the hipError_t of the launch) ----
 uint32_t tile_count_for(uint64_t n_groups);
 bool needs_tile_offsets(uint64_t n_groups);  // the scatter pass wants one uint64 list offset per tile (scan_tiles_kernel)
@@ -92,6 +105,9 @@ hipError_t launch_classify_views(const SceneDev &s, const float4 *spheres, bool 
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
                           uint64_t *total, bool streaming, hipStream_t st);
+// scatter + commands of n_views (<= MCULL_MAX_VIEWS) views of one scene in three launches; leaves every view's tile counters zero
+hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint32_t n_views, const ViewTail *views, bool streaming,
+                                hipStream_t st);
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
                                 uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st,
