@@ -1076,7 +1076,7 @@ struct ViewSet {
 // and 8 views.  A byte that only says "outside the frustum" did not pay in front of a pass that waited for its texel
 // reads: 5.35 against 5.14 ms for 8 views at 8192^2.  With the occlusion verdicts and the tests it lets the pass leave
 // out, it does.)
-__global__ __launch_bounds__(kBlock) void classify_views_kernel(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void classify_views_kernel(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
                                                                 const float *__restrict__ rmax, uint32_t per_instance_sphere,
                                                                 uint32_t n_instances, ViewSet vs, const ViewConst *__restrict__ view_dev,
                                                                 uint2 *__restrict__ flags, uint32_t *__restrict__ useful) {
