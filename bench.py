@@ -435,6 +435,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     kernel_ms = []
     gathered = [None, None]
     if multi:
+        gather_buf = [torch.empty((world * (n_rows + 1), 2), device=device, dtype=torch.int32) for _ in range(2)]
+        gather_out = [torch.empty((2, world), device=device, dtype=torch.int64) for _ in range(2)]
         comm = torch.cuda.Stream(device=device)
         ev_cull = [torch.cuda.Event() for _ in range(2)]
         ev_comm = [torch.cuda.Event() for _ in range(2)]
@@ -481,7 +483,10 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_cull[b])
 
-                gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b].cpu() if args.rehearse_shared_gpu else cmds_packed[b])
+                if args.rehearse_shared_gpu:
+                    gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b].cpu())
+                else:
+                    gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b], gathered=gather_buf[b], out=gather_out[b])
                 if gather_lists:
                     env.mdist.gather_visible_lists(lst, gathered[b][0])
                 ev_comm[b].record(comm)

@@ -87,20 +87,27 @@ def gather_visible_lists(list_local, totals_all, out=None, group=None, first_ins
     return out[:total]
 
 
-def rebase_gathered(gathered, world, rows):
+_package = None  # the ctypes binding, imported on first use (this module is importable without the library)
+
+
+def rebase_gathered(gathered, world, rows, out=None):
     """`gathered` (int32 [world * rows, 2]): per rank rows - 1 {taskCount, firstTask} records with rank-local
     firstTask and one record holding the rank's visible count (uint64).  Adds the counts of the lower ranks to
     every firstTask in place (modulo 2^32 like the 32-bit field it is) and returns (totals_all int64 [world],
     cmds_all int32 [world, rows - 1, 2], a view of `gathered`).  On the GPU this is one launch of the
-    library (mcull_rebase_gathered_commands) on the current stream; on the CPU (gloo) a few tensor ops."""
+    library (mcull_rebase_gathered_commands) on the current stream; on the CPU (gloo) a few tensor ops.
+    `out` (optional, GPU): an int64 [2, world] tensor for the totals and bases, reused by a frame loop."""
     g = gathered.view(world, rows, 2)
     if gathered.is_cuda:
-        import importlib
+        global _package
+        if _package is None:
+            import importlib
 
-        mc = importlib.import_module(__package__)
-        out = torch.empty((2, world), dtype=torch.int64, device=gathered.device)
-        mc.rebase_gathered_commands(torch.cuda.current_stream(gathered.device).cuda_stream, gathered.data_ptr(), world, rows - 1,
-                                    out[0].data_ptr(), out[1].data_ptr())
+            _package = importlib.import_module(__package__)
+        if out is None:
+            out = torch.empty((2, world), dtype=torch.int64, device=gathered.device)
+        _package.rebase_gathered_commands(torch.cuda.current_stream(gathered.device).cuda_stream, gathered.data_ptr(), world, rows - 1,
+                                          out[0].data_ptr(), out[1].data_ptr())
         return out[0], g[:, : rows - 1, :]
     return rebase_gathered_tensor_ops(gathered, world, rows)
 
@@ -117,19 +124,22 @@ def rebase_gathered_tensor_ops(gathered, world, rows):
     return totals_all, cmds_all
 
 
-def gather_draw_list_packed(cmds_packed, group=None):
+def gather_draw_list_packed(cmds_packed, group=None, gathered=None, out=None):
     """The same global description with ONE collective per frame.  cmds_packed: int32 tensor
     [n_local + 1, 2]: rows 0..n_local-1 are the rank's {taskCount, firstTask} with rank-local
     firstTask, and row n_local holds the rank's visible count as a little-endian uint64 (pass the
     address of that row as mcull_cull_params.total: the cull writes the count straight into it).
     All ranks' buffers are gathered at once and every rank rebases the gathered firstTask values
     itself from the gathered counts (rebase_gathered: no second collective and no host round trip).
+    `gathered` ([world * (n_local + 1), 2], same dtype and device) and `out` (see rebase_gathered): buffers a frame
+    loop keeps instead of allocating per frame.
     Returns (totals_all int64 [world], cmds_all int32 [world, n_local, 2])."""
     world = dist.get_world_size(group)
     rows = cmds_packed.shape[0]
-    gathered = torch.empty((world * rows, 2), dtype=cmds_packed.dtype, device=cmds_packed.device)
+    if gathered is None:
+        gathered = torch.empty((world * rows, 2), dtype=cmds_packed.dtype, device=cmds_packed.device)
     dist.all_gather_into_tensor(gathered, cmds_packed, group=group)
-    return rebase_gathered(gathered, world, rows)
+    return rebase_gathered(gathered, world, rows, out)
 
 
 def merge_depth(depth, group=None):
