@@ -149,6 +149,10 @@ def _rank_main(rank, world, port, out_dir):
     packed[-1] = torch.from_numpy(np.array([r.total], dtype="<u8").view("<i4").copy())
     totals_p, cmds_p = D.gather_draw_list_packed(packed)
     assert torch.equal(totals_p, totals_all) and torch.equal(cmds_p.reshape(-1, 2), cmds_all)
+    # the same into a buffer the caller keeps from frame to frame
+    kept = torch.full((world * packed.shape[0], 2), -1, dtype=torch.int32)
+    totals_k, cmds_k = D.gather_draw_list_packed(packed, gathered=kept)
+    assert torch.equal(totals_k, totals_all) and torch.equal(cmds_k.reshape(-1, 2), cmds_all) and cmds_k.data_ptr() == kept.data_ptr()
     # optional third step: the packed global list (drawIDs made global before the gather)
     cap = len(ml) * (n_inst // world + 1)
     lst = torch.zeros((cap, 2), dtype=torch.int32)
