@@ -361,12 +361,27 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     if workload == "config3":
         n_scene, per = (args.instances or 1_000_000), (args.meshlets_per_instance or 13916)
         first, n_inst = shard_range(n_scene, world, rank) if strong else (0, n_scene)
-        c_np, s_np = env.host.synthetic_bounds(per, seed=5)  # one shared mesh
-        cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
         xf = make_transforms_range(device, first, n_inst, 70.0, 77 if strong else 77 + rank)
-        torch.cuda.synchronize()
         ctx.set_instance_ranges(None, None)
-        ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=per, mem=mc.MEM_DEVICE, adopt=True)
+        if args.c3_mesh == "proxy" and not args.meshlets_per_instance:
+            # the stand-in for dragon.obj (871 200 triangles) through the product's own load-time pipeline: dedup,
+            # reorder, meshlets, bounds; consecutive meshlets are neighbours on the surface, as in any real mesh
+            pos, tris = env.host.proxy_mesh(660, 660, seed=12)
+            cor = np.full((tris.size, 3), -1, dtype="<i4")
+            cor[:, 0] = tris.reshape(-1)
+            mesh = ctx.mesh_from_arrays(pos, cor).optimize()
+            ctx.build_meshlets(mesh)  # leaves meshlets, geometry and bounds uploaded
+            per = len(mesh.meshlets)
+            ml = ctx.download_meshlets(per)
+            c_np = np.ascontiguousarray(ml["cone"])
+            s_np = np.ascontiguousarray(np.concatenate([ml["coneApex"][:, :3], ml["radius"][:, None]], axis=1))
+            cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
+            torch.cuda.synchronize()
+        else:
+            c_np, s_np = env.host.synthetic_bounds(per, seed=5)  # one shared "mesh" of unrelated meshlets in a unit cube
+            cone, sphere = torch.from_numpy(c_np).to(device), torch.from_numpy(s_np).to(device)
+            torch.cuda.synchronize()
+            ctx.upload_bounds_soa(cone.data_ptr(), sphere.data_ptr(), count=per, mem=mc.MEM_DEVICE, adopt=True)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         off = cnt = None
         g = env.host.create_globals(eye=(90.0, 85.0, 60.0), width=3840, height=2160, flip_y=False, meshlet_count=per)
@@ -525,6 +540,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
             with_lists = {"ms_per_step": round(el2 / n2 * 1e3, 4), "value": round(job_pairs * n_views / (el2 / n2) / 1e9, 3),
                           "list_bytes_per_rank": int(totals_all.max()) * 8 * world}
     pre_marked, pre_tested, pre_per_group = ctx.precull_stats()  # of the last timed cull (view slot 0)
+    grp_dropped, grp_tested = ctx.precull_group_stats()
     hiz_pairs = 0
     if use_hiz and workload == "config4":
         # pairs that reach the occlusion test (one 4-byte texel each in the algorithmic bytes): the survivors
@@ -543,7 +559,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 kernel_ms=float(np.mean(kernel_ms)), visible=visible, job_visible=job_visible, with_lists=with_lists,
                 n_inst=n_inst, n_scene=n_scene, per=per, n_pairs=n_pairs, job_pairs=job_pairs, n_views=n_views, unique=unique,
                 tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
-                precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances"),
+                precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances",
+                             **({"group_level": {"dropped": grp_dropped, "tested": grp_tested}} if grp_tested else {})),
                 value=job_pairs * n_views / (elapsed / steps) / 1e9,
                 scene=(cone, sphere, xf, off, cnt))
 
@@ -595,9 +612,11 @@ def run_cull(env, workload):
                     "every step, frustum+cone+hiz, ordered compaction, %s (visible fraction is the last view's)"
                     % (n_inst, per, "one pass over the bounds for all views" if not args.separate_views else "one cull per view"))
         elif workload == "config3":
-            name = ("config 3: %d instances of one %d-meshlet mesh = %d meshlet-instances per GPU, frustum+cone+hiz against a "
+            name = ("config 3: %d instances of one %d-meshlet mesh (%s) = %d meshlet-instances per GPU, frustum+cone+hiz against a "
                     "3840x2160 pyramid (unflipped projection), ordered compaction; bounds are shared, so the HBM figure "
-                    "counts little more than the visible list and excludes the Hi-Z texel reads" % (n_inst, per, n_pairs))
+                    "counts little more than the visible list and excludes the Hi-Z texel reads"
+                    % (n_inst, per, "the 871 200-triangle stand-in for dragon.obj, meshletised by the library"
+                       if args.c3_mesh == "proxy" and not args.meshlets_per_instance else "unrelated random meshlets in a unit cube", n_pairs))
         else:
             name = ("config 4: synthetic scene, %d instances x %d unique meshlets = %d meshlet-instances per GPU, frustum+cone%s, "
                     "%s compaction" % (n_inst, per, n_pairs,
@@ -1044,6 +1063,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--c3-mesh", default="proxy", choices=["proxy", "random"],
+                    help="config3: the mesh every instance draws - the procedural stand-in for dragon.obj built by the library's "
+                         "mesh pipeline (default), or 13 916 unrelated random meshlets (the scene of the earlier measurements)")
     ap.add_argument("--workload", default="config4", choices=["config4", "config1", "config3", "config5", "hiz", "bounds", "depth", "meshbuild", "rendezvous"])
     ap.add_argument("--instances", type=int, default=0, help="override the workload's instance count")
     ap.add_argument("--meshlets-per-instance", type=int, default=0)

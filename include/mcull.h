@@ -382,6 +382,13 @@ int mcull_slow_path_pairs(mcull_ctx *ctx, uint64_t *pairs);
  * views).  No reference counterpart. */
 int mcull_precull_stats(mcull_ctx *ctx, uint64_t *marked, uint64_t *tested, int *per_group);
 
+/* The same for the GROUP level, which follows the instance level in scenes whose instances span 32 and more
+ * 64-meshlet groups with bounds small enough to stay in the caches (one large mesh drawn many times): every group of the
+ * surviving instances is tested once more with an enclosing sphere of its own, in the same two ways, before any of
+ * its meshlets is loaded.  *tested = groups of the instances the instance level kept, *dropped = those of them the
+ * group level removed; 0 / 0 when it did not run.  Synchronous.  No reference counterpart. */
+int mcull_precull_group_stats(mcull_ctx *ctx, uint64_t *dropped, uint64_t *tested);
+
 /* Device timestamps around the kernels of each mcull_cull / mcull_hiz_build /
  * mcull_compute_bounds (HIP events on the context's stream; the reference's timestamp
  * queries, Engine.cpp:2393-2394, :2548).  Off by default: the two event records cost a few

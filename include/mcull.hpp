@@ -197,6 +197,13 @@ public:
         s.perGroup = per_group != 0;
         return s;
     }
+    // and its group level (instances of 32 groups and more): {dropped, tested} groups
+    struct GroupStats { uint64_t dropped, tested; };
+    GroupStats precullGroupStats() {
+        GroupStats s{0, 0};
+        MCULL_CHECK(ctx_, mcull_precull_group_stats(ctx_, &s.dropped, &s.tested));
+        return s;
+    }
     uint64_t visibleCount() {
         uint64_t n = 0;
         MCULL_CHECK(ctx_, mcull_download_count(ctx_, &n));

@@ -28,7 +28,7 @@ calls = {
  "mcull_cull_device_globals": (None, P, 1, None, None), "mcull_cull_views_device_globals": (None, 1, P, 1, None, None),
  "mcull_rebase_commands": (None, P, 0), "mcull_rebase_gathered_commands": (None, None, 1, 1, None, None), "mcull_task_payload_count": (None,), "mcull_emit_task_payloads": (None, P),
  "mcull_download_count": (None, None), "mcull_download_list": (None, P, 1, None), "mcull_download_commands": (None, P, 8),
- "mcull_download_mask": (None, P, 1), "mcull_precull_stats": (None, None, None, None), "mcull_slow_path_pairs": (None, None), "mcull_enable_timing": (None, 1), "mcull_last_kernel_ms": (None, None),
+ "mcull_download_mask": (None, P, 1), "mcull_precull_stats": (None, None, None, None), "mcull_precull_group_stats": (None, None, None), "mcull_slow_path_pairs": (None, None), "mcull_enable_timing": (None, 1), "mcull_last_kernel_ms": (None, None),
  "mcull_depth_rasterize": (None, P, 4, 4, 1), "mcull_depth_rasterize_device_globals": (None, P, 4, 4, 1),
  "mcull_depth_buffer": (None, None, None, None), "mcull_depth_download": (None, P), "mcull_scene_upload": (None, b"/nonexistent"),
  "mcull_mesh_upload": (None, None), "mcull_mesh_build_meshlets_gpu": (None, None),

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mcull_mesh_save", "mcull_mesh_destroy", "mcull_mesh_from_arrays_gpu", "mcull_mesh_build_meshlets_gpu", "mcull_cull_views", "mcull_select_result",
     "mcull_create_globals", "mcull_extract_frustum", "mcull_reference_transforms", "mcull_create_indirect_buffer",
     "mcull_cull_device_globals", "mcull_depth_rasterize_device_globals",
-    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_slow_path_pairs", "mcull_rebase_gathered_commands",
+    "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_precull_group_stats", "mcull_slow_path_pairs", "mcull_rebase_gathered_commands",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
 ]
@@ -117,6 +117,7 @@ _sig("mcull_cull", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
 _sig("mcull_cull_static", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
 _sig("mcull_slow_path_pairs", _I, [_P, C.POINTER(_U64)])
 _sig("mcull_precull_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_I)])
+_sig("mcull_precull_group_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)])
 _sig("mcull_rebase_commands", _I, [_P, _P, _U32])
 _sig("mcull_rebase_gathered_commands", _I, [_P, _P, _U32, _U64, _P, _P])
 _sig("mcull_task_payload_count", _U64, [_P])
@@ -611,6 +612,13 @@ class Context:
         m, t, pg = _U64(), _U64(), _I()
         self._chk(lib.mcull_precull_stats(self._h, C.byref(m), C.byref(t), C.byref(pg)))
         return int(m.value), int(t.value), bool(pg.value)
+
+    def precull_group_stats(self):
+        """(dropped, tested) of the last cull's group level: 64-meshlet groups of the instances the instance level
+        kept, and how many of them went before any of their meshlets was loaded; (0, 0) when it did not run."""
+        d, t = _U64(), _U64()
+        self._chk(lib.mcull_precull_group_stats(self._h, C.byref(d), C.byref(t)))
+        return int(d.value), int(t.value)
 
     def download_count(self):
         n = _U64()

@@ -550,12 +550,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 // R = +inf: such a range is never pre-culled.
 // rmax[i] >= every meshlet radius of the range (what bounds the mip level its meshlets can select); +inf with R,
 // and when a radius of the range is negative (the sign of the projected radius then differs inside the range).
+// sliding: sphere i encloses the meshlets [i, i + 64) of an array of uniform_count meshlets instead - whatever group
+// of at most 64 meshlets starts at meshlet i, of any range, lies inside it.
 __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__restrict__ centre_radius,
                                                               const uint2 *__restrict__ ranges, uint32_t uniform_count,
-                                                              float4 *__restrict__ spheres, float *__restrict__ rmax) {
+                                                              uint32_t sliding, float4 *__restrict__ spheres,
+                                                              float *__restrict__ rmax) {
     __shared__ float s_red[kWaves][4];
     const uint32_t i = blockIdx.x;
-    const uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
+    uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
+    if (sliding) {
+        first = i;
+        count = uniform_count - i < 64u ? uniform_count - i : 64u;
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (count == 0u || count > (1u << 20)) {
         if (threadIdx.x == 0) {
@@ -760,11 +767,9 @@ struct InstanceGeom {
     float wx, wy, wz, F, R, rmax_local, ax, ay, az;
 };
 
-__device__ __forceinline__ InstanceGeom instance_geometry(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
-                                                          const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i) {
+__device__ __forceinline__ InstanceGeom sphere_geometry(const float4 *__restrict__ transforms, uint32_t i, float4 sp, float rmax_local) {
     const float4 *t = transforms + (size_t)i * 4;
     const float4 c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
-    const float4 sp = spheres[per_instance_sphere ? i : 0u];
     const float R = sp.w;
     const float wx = ((c0.x * sp.x + c1.x * sp.y) + c2.x * sp.z) + c3.x;
     const float wy = ((c0.y * sp.x + c1.y * sp.y) + c2.y * sp.z) + c3.y;
@@ -784,13 +789,20 @@ __device__ __forceinline__ InstanceGeom instance_geometry(const float4 *__restri
     const float ax = ((fabsf(c0.x) * ex + fabsf(c1.x) * ey) + fabsf(c2.x) * ez) + fabsf(c3.x);
     const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
     const float az = ((fabsf(c0.z) * ex + fabsf(c1.z) * ey) + fabsf(c2.z) * ez) + fabsf(c3.z);
-    return InstanceGeom{wx, wy, wz, F, R, rmax[per_instance_sphere ? i : 0u], ax, ay, az};
+    return InstanceGeom{wx, wy, wz, F, R, rmax_local, ax, ay, az};
 }
 
-__device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, const ViewConst &v, bool want_more) {
+__device__ __forceinline__ InstanceGeom instance_geometry(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+                                                          const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i) {
+    const uint32_t k = per_instance_sphere ? i : 0u;
+    return sphere_geometry(transforms, i, spheres[k], rmax[k]);
+}
+
+// tests: the tests to reason about (v.tests, or fewer when a coarser level has already settled some)
+__device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, const ViewConst &v, bool want_more, uint32_t tests) {
     const float wx = q.wx, wy = q.wy, wz = q.wz, F = q.F, R = q.R, rmax_local = q.rmax_local, ax = q.ax, ay = q.ay, az = q.az;
     bool outside = false, inside = rmax_local < 1.0e18f;  // +inf: a negative or non-finite radius in the range
-    if (v.tests & MCULL_TEST_FRUSTUM) {
+    if (tests & MCULL_TEST_FRUSTUM) {
 #pragma unroll
         for (int p = 0; p < 5; p++) {
             const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2], d = v.frustum[p][3];
@@ -806,7 +818,7 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
     }
     if (outside) return kInstCulled;
     uint32_t flags = (want_more && inside) ? kInstInside : 0u;
-    if ((v.tests & MCULL_TEST_HIZ) && v.pyramid) {
+    if ((tests & MCULL_TEST_HIZ) && v.pyramid) {
         // every meshlet centre, as the per-meshlet path evaluates it, lies within rho of (wx, wy, wz): F R in real
         // numbers, plus the roundoff of both evaluations (a few 2^-24 of ax + ay + az)
         const float rho = (F * R) * 1.0001f + ((ax + ay) + az) * 1.52587890625e-5f;
@@ -821,7 +833,7 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
 __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
                                                       const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i,
                                                       const ViewConst &v, bool want_more) {
-    return classify_geometry(instance_geometry(transforms, spheres, rmax, per_instance_sphere, i), v, want_more);
+    return classify_geometry(instance_geometry(transforms, spheres, rmax, per_instance_sphere, i), v, want_more, v.tests);
 }
 
 // The pre-pass of a single-view cull: the WORK LIST of the mask pass (layout above; work[0] is zero on entry).
@@ -837,10 +849,11 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
                                                                   uint32_t groups_per_instance, uint64_t units, ViewConst v_arg,
                                                                   const ViewConst *__restrict__ view_dev, const float *__restrict__ rmax,
                                                                   uint32_t *__restrict__ work, uint64_t *__restrict__ zero_mask,
-                                                                  uint32_t want_flags) {
+                                                                  uint32_t want_flags, uint32_t *__restrict__ next_list) {
     const ViewConst &v = view_dev ? *view_dev : v_arg;
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_base;
+    if (next_list && blockIdx.x == 0 && threadIdx.x == 0) next_list[0] = 0u;  // the group level's list starts empty
     const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
     bool outside[kPreItems];
     uint32_t hand_on[kPreItems];  // kInstInside / kInstOpen in bits 30 and 31 of the survivor's list entries (want_flags)
@@ -891,6 +904,86 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
     }
 }
 
+// The GROUP level (no counterpart in the reference either): scenes whose instances span many 64-meshlet groups -
+// one large mesh drawn many times - leave the instance level with survivors of which most groups are still hidden
+// or outside: an instance that straddles an occluder's edge, or the frustum's, keeps all of its groups.  Every group
+// that starts at meshlet m lies inside sphere m of a second table (range_sphere_kernel, sliding: the sphere of the
+// meshlets [m, m + 64), which depends on the bounds alone), and the same two proofs run per listed group:
+// what the instance level has settled for the whole instance (bits 30 / 31 of its entries) is not looked at again,
+// a group that is certainly rejected leaves the list, and a group that lies inside all planes or in the open is told
+// so.  in: the instance level's list; out: a list of the same layout for ranged scenes, and for uniform scenes one
+// uint32 per group, the group's index in the scene with the two bits on top (hence fewer than 2^30 groups).
+// A fixed number of workgroups walks the input (its length is device data); each reserves room for the survivors
+// among its kBlock * kGrpItems entries with one atomic.  out[0] is zero on entry (instance_precull_kernel).
+constexpr int kGrpItems = 4;
+
+template <bool RANGED>
+__global__ __launch_bounds__(kBlock) void group_precull_kernel(const float4 *__restrict__ transforms,
+                                                               const float4 *__restrict__ gspheres, const float *__restrict__ grmax,
+                                                               uint32_t groups_per_instance, uint64_t units, ViewConst v_arg,
+                                                               const ViewConst *__restrict__ view_dev,
+                                                               const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
+    const ViewConst &v = view_dev ? *view_dev : v_arg;
+    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_base;
+    const uint32_t n_in = RANGED ? in[0] : in[0] * groups_per_instance;
+    const uint4 *in_rec = reinterpret_cast<const uint4 *>(in + work_rec_offset_words(units));
+    uint4 *out_rec = reinterpret_cast<uint4 *>(out + work_rec_offset_words(units));
+    constexpr uint32_t kPerBlock = kBlock * kGrpItems;
+    for (uint32_t b = blockIdx.x; (unsigned long long)b * kPerBlock < n_in; b += gridDim.x) {
+        const uint32_t i0 = b * kPerBlock + threadIdx.x * kGrpItems;
+        uint32_t entry[kGrpItems], keep[kGrpItems], mine = 0;
+        uint4 rec[kGrpItems];
+#pragma unroll
+        for (int q = 0; q < kGrpItems; q++) {
+            keep[q] = 0u;
+            entry[q] = 0u;
+            rec[q] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t idx = i0 + q;
+            if (idx >= n_in) continue;
+            uint32_t inst, settled, sphere, g;  // sphere: the group's first meshlet
+            if (RANGED) {
+                g = in[kWorkHeader + idx];
+                rec[q] = in_rec[idx];
+                inst = rec[q].x;
+                settled = rec[q].w >> 30;
+                sphere = rec[q].y;
+            } else {
+                const uint32_t item = idx / groups_per_instance, e = in[kWorkHeader + item];
+                const uint32_t local_group = idx - item * groups_per_instance;
+                inst = e & 0x3fffffffu;
+                settled = e >> 30;
+                sphere = local_group * 64u;
+                g = inst * groups_per_instance + local_group;
+            }
+            // bit 0: no meshlet of the instance is rejected by the frustum test; bit 1: none by the occlusion test
+            const uint32_t tests = v.tests & ~(((settled & 1u) ? (uint32_t)MCULL_TEST_FRUSTUM : 0u) | ((settled & 2u) ? (uint32_t)MCULL_TEST_HIZ : 0u));
+            uint32_t f = 0u;
+            if (tests & (MCULL_TEST_FRUSTUM | MCULL_TEST_HIZ))
+                f = classify_geometry(sphere_geometry(transforms, inst, gspheres[sphere], grmax[sphere]), v, true, tests);
+            if (f & kInstCulled) continue;
+            settled |= ((f & kInstInside) ? 1u : 0u) | ((f & kInstOpen) ? 2u : 0u);
+            keep[q] = 1u;
+            entry[q] = RANGED ? g : (g | (settled << 30));
+            if (RANGED) rec[q].w = (rec[q].w & 0x3fffffffu) | (settled << 30);
+            mine++;
+        }
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(mine, s_wave, &total);
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(&out[0], total) : 0u;
+        __syncthreads();
+        uint32_t pos = s_base + excl;
+#pragma unroll
+        for (int q = 0; q < kGrpItems; q++) {
+            if (!keep[q]) continue;
+            out[kWorkHeader + pos] = entry[q];
+            if (RANGED) out_rec[pos] = rec[q];
+            pos++;
+        }
+        __syncthreads();  // s_base is rewritten by the next block
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ordered, pass 1: visibility ballots.  Small workgroups: each of the 4 waves takes NG consecutive
 // groups.  The workgroup first stages the 4*NG group records in LDS, then requests every group's
@@ -914,9 +1007,13 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v_arg,
     uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous,
-    const ViewConst *__restrict__ view_dev, const uint32_t *__restrict__ work, uint32_t *__restrict__ kept_report) {
+    const ViewConst *__restrict__ view_dev, const uint32_t *__restrict__ work, uint32_t *__restrict__ kept_report,
+    uint32_t list_of_groups) {
     const ViewConst &v = VP ? *view_dev : v_arg;
     const uint32_t tests = (VP || FLAGS) ? v.tests : TESTS;
+    // FLAGS only: the list of a scene without per-instance ranges holds one entry per group (group_precull_kernel), not
+    // one per instance
+    const bool per_group = FLAGS && list_of_groups != 0u;
     constexpr uint32_t kGroups = kWaves * NG;  // groups per workgroup
     __shared__ uint4 s_rec[kGroups];
     __shared__ uint32_t s_keep[kGroups];  // FLAGS: the tests each slot's group still needs
@@ -938,7 +1035,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     // next block's loads only after the last one's arithmetic, 4.9 against 6.4 TB/s.)  Every other form runs the
     // loop's body exactly once.
     uint32_t n_list = 0;
-    if constexpr (FLAGS) n_list = group_rec ? work[0] : work[0] * groups_per_instance;
+    if constexpr (FLAGS) n_list = (group_rec || per_group) ? work[0] : work[0] * groups_per_instance;
     for (uint32_t b = FLAGS ? blockIdx.x : first_block;; b += gridDim.x) {
     if (FLAGS && (unsigned long long)b * kGroups >= n_list) break;
     const uint32_t block_g0 = b * kGroups;
@@ -961,7 +1058,11 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
             gi.inst = r.x; gi.first_meshlet = r.y; gi.count = r.z; gi.local_group = r.w;
             if (FLAGS) { hand_on = r.w >> 30; gi.local_group = r.w & 0x3fffffffu; }
         } else {
-            if (work) {
+            if (work && per_group) {
+                const uint32_t e = work[kWorkHeader + wc];
+                hand_on = e >> 30;
+                g = e & 0x3fffffffu;
+            } else if (work) {
                 const uint32_t item = wc / groups_per_instance;
                 uint32_t e = work[kWorkHeader + item];
                 if (FLAGS) { hand_on = e >> 30; e &= 0x3fffffffu; }
@@ -971,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
         }
     }
     uint32_t n_run = n_groups;
-    if (work) n_run = group_rec ? work[0] : work[0] * groups_per_instance;
+    if (work) n_run = (group_rec || per_group) ? work[0] : work[0] * groups_per_instance;
     // how much the pre-cull kept, left where the host can look at it later without waiting (host-mapped memory)
     if (!FLAGS && work && kept_report && blockIdx.x == 0 && threadIdx.x == 0) *kept_report = work[0];
     if (block_g0 >= n_run) return;  // workgroups beyond the list's end
@@ -1087,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         const InstanceGeom q = instance_geometry(transforms, spheres, rmax, per_instance_sphere, i);
         for (uint32_t slot = 0; slot < vs.n; slot++) {
             const ViewConst &v = view_dev ? view_dev[slot] : vs.v[slot];
-            const uint32_t f = classify_geometry(q, v, true);
+            const uint32_t f = classify_geometry(q, v, true, v.tests);
             found += f != 0u;
             if (slot < 4u) lo |= f << (8u * slot);
             else hi |= f << (8u * (slot - 4u));
@@ -1684,46 +1785,48 @@ bool needs_tile_offsets(uint64_t n_groups) { return tile_count_for(n_groups) > k
 
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
-                               const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report, bool flags, hipStream_t st) {
+                               const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report, bool flags, bool list_of_groups,
+                               hipStream_t st) {
     const uint32_t per_block = kWaves * NG;
+    const uint32_t log = (flags && work && list_of_groups && !s.group_rec) ? 1u : 0u;
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
     if (flags && work) {
         const uint32_t walkers = grid < 16384u ? grid : 16384u;  // the FLAGS form walks the list with a stride
         if (view_dev)
             hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true, true>), dim3(walkers), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                                s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                               tile_counts, 0u, view_dev, work, kept_report);
+                               tile_counts, 0u, view_dev, work, kept_report, log);
         else
             hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, false, true>), dim3(walkers), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                                s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                               tile_counts, 0u, (const ViewConst *)nullptr, work, kept_report);
+                               tile_counts, 0u, (const ViewConst *)nullptr, work, kept_report, log);
         return;
     }
     if (view_dev) {
         hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                            s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                           tile_counts, 0u, view_dev, work, kept_report);
+                           tile_counts, 0u, view_dev, work, kept_report, 0u);
         return;
     }
     MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
                                                      s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                      s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
-                                                     (const ViewConst *)nullptr, work, kept_report));
+                                                     (const ViewConst *)nullptr, work, kept_report, 0u));
 }
 
 // view_dev != nullptr: the kernels take the view constants (and the tests) from that device record
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report,
-                            bool flags) {
+                            bool flags, bool list_of_groups) {
     // groups per wave: more requests in flight per wave for big scenes, enough workgroups to fill
     // 256 CUs for small ones
     if (streaming) {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, st);
-        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
+        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
     } else {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, st);
-        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, st);
-        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, st);
+        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
+        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
+        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
     }
     return hipGetLastError();
 }
@@ -1894,8 +1997,17 @@ size_t range_sphere_bytes(uint32_t n_ranges) { return (size_t)n_ranges * 20; }
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st) {
     if (n_ranges == 0) return hipSuccess;
-    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, spheres,
+    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, 0u, spheres,
                        reinterpret_cast<float *>(spheres + n_ranges));
+    return hipGetLastError();
+}
+
+// sphere m = the meshlets [m, m + 64) of the n_meshlets uploaded (range_sphere_bytes(n_meshlets) bytes): encloses every
+// group that starts at meshlet m
+hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st) {
+    if (n_meshlets == 0) return hipSuccess;
+    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_meshlets), dim3(kBlock), 0, st, centre_radius, (const uint2 *)nullptr, n_meshlets, 1u,
+                       spheres, reinterpret_cast<float *>(spheres + n_meshlets));
     return hipGetLastError();
 }
 
@@ -1905,13 +2017,32 @@ size_t work_list_bytes(uint64_t units, bool ranged) { return work_rec_offset_wor
 // the ballot words, of which the pre-pass zeroes those of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
-                                   bool want_flags, hipStream_t st) {
+                                   bool want_flags, hipStream_t st, uint32_t *next_list) {
     if (s.n_instances == 0) return hipSuccess;
     const uint32_t per_block = kBlock * kPreItems;
     const float *rmax = reinterpret_cast<const float *>(spheres + (per_instance_sphere ? s.n_instances : 1u));
     hipLaunchKernelGGL(instance_precull_kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kBlock), 0, st, s.transforms,
                        spheres, per_instance_sphere ? 1u : 0u, s.ranges, group_base, s.n_instances, s.groups_per_instance,
-                       group_base ? s.n_groups : (uint64_t)s.n_instances, v, view_dev, rmax, work, zero_mask, want_flags ? 1u : 0u);
+                       group_base ? s.n_groups : (uint64_t)s.n_instances, v, view_dev, rmax, work, zero_mask, want_flags ? 1u : 0u, next_list);
+    return hipGetLastError();
+}
+
+// The group level between the instance level and the mask pass: `in` = the instance level's list (with the bits of
+// want_flags), `out` = work_list_bytes(n_groups, ranged) bytes whose first word is zero by then (next_list above);
+// gspheres = what launch_group_spheres wrote for the n_meshlets uploaded.
+hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint32_t n_meshlets, const ViewConst &v,
+                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st) {
+    if (s.n_groups == 0) return hipSuccess;
+    const bool ranged = s.group_rec != nullptr;
+    const float *grmax = reinterpret_cast<const float *>(gspheres + n_meshlets);
+    const uint64_t blocks = (s.n_groups + kBlock * kGrpItems - 1) / (kBlock * kGrpItems);
+    const uint32_t walkers = blocks < 4096u ? (uint32_t)blocks : 4096u;
+    if (ranged)
+        hipLaunchKernelGGL(group_precull_kernel<true>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
+                           s.groups_per_instance, s.n_groups, v, view_dev, in, out);
+    else
+        hipLaunchKernelGGL(group_precull_kernel<false>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
+                           s.groups_per_instance, s.n_groups, v, view_dev, in, out);
     return hipGetLastError();
 }
 

@@ -100,6 +100,10 @@ struct mcull_ctx {
     DevBuf range_spheres;
     bool spheres_valid = false, spheres_ranged = false;
     uint32_t spheres_uniform_count = 0;
+    // group level of the pre-cull (scenes whose instances span many groups): sphere m encloses the meshlets [m, m + 64)
+    DevBuf group_spheres;
+    bool gspheres_valid = false;
+    bool precull_groups = true;  // MCULL_PRECULL_GROUPS=0: no group level (measurements)
     // A pre-cull that removes next to nothing costs its own pass and a slower mask pass (100 M pairs, all in
     // view: 0.77 against 0.69 ms).  Each single-view cull that runs it leaves the number of units it kept in
     // host-mapped memory (kept_host[slot], read later without waiting); when that was more than 90 % of the
@@ -147,9 +151,10 @@ struct mcull_ctx {
         // instances; nullptr when it did not run
         const uint32_t *work = nullptr;
         uint64_t precull_units = 0;
+        const uint32_t *group_work = nullptr;  // the group level's list (one entry per surviving group), when it ran
     };
     struct ViewOut {
-        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, work;
+        DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, work, group_work;
         uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
         bool counters_clean = false;   // tile counters are all zero (the mask pass adds into them, the command pass re-zeroes)
         uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
@@ -343,6 +348,7 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     // for evaluation and tests (results are identical)
     if (const char *hs = std::getenv("MCULL_HIZ_STRIPS")) c->hiz_strips = hs[0] != '0';
     if (const char *pf = std::getenv("MCULL_PRECULL_FLAGS")) c->precull_flags = pf[0] != '0';
+    if (const char *pg = std::getenv("MCULL_PRECULL_GROUPS")) c->precull_groups = pg[0] != '0';
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
     const char *fs = std::getenv("MCULL_FORCE_STREAMING");
@@ -372,10 +378,11 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
                       &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->view_flags, &c->depth, &c->view_dev, &c->raster_scratch,
-                      &c->range_spheres};
+                      &c->range_spheres, &c->group_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
-        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.work})
+        for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.work,
+                           &o.group_work})
             release(*b);
     for (auto &s : c->hiz) { release(s.pyramid); release(s.table); release(s.strips); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -413,7 +420,7 @@ int mcull_upload_meshlets(mcull_ctx *c, const mcull_meshlet *meshlets, uint64_t 
     c->have_aos = true;
     c->geometry_checked = false;
     c->have_bounds = true;
-    c->spheres_valid = false;  // the pre-cull's range spheres derive from the bounds
+    c->spheres_valid = c->gspheres_valid = false;  // the pre-cull's range spheres derive from the bounds
     invalidate_results(c);
     return MCULL_OK;
 }
@@ -443,7 +450,7 @@ int mcull_upload_bounds_soa(mcull_ctx *c, const float *cone_axis_w, const float 
     c->n_meshlets = count;
     c->have_aos = false;
     c->have_bounds = true;
-    c->spheres_valid = false;
+    c->spheres_valid = c->gspheres_valid = false;
     invalidate_results(c);
     return MCULL_OK;
 }
@@ -517,7 +524,7 @@ int mcull_compute_bounds(mcull_ctx *c) {
         c->timed = true;
     }
     c->have_bounds = true;
-    c->spheres_valid = false;
+    c->spheres_valid = c->gspheres_valid = false;
     return MCULL_OK;
 }
 
@@ -553,7 +560,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
     if (!c) return MCULL_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     invalidate_results(c);
-    c->spheres_valid = false;
+    c->spheres_valid = c->gspheres_valid = false;
     if (!meshlet_offset || !meshlet_count) {
         c->have_ranges = false;
         return MCULL_OK;
@@ -713,6 +720,8 @@ struct CullPlan {
     uint32_t n_tiles;
     uint32_t *work;             // work list of this cull's instance pre-cull, nullptr when it does not run
     uint64_t precull_units;     // groups (ranged scenes) or instances it decides about
+    bool hand_on;               // the list's entries carry what the instance level has settled (cull_mask_kernel<..., FLAGS>)
+    uint32_t *group_work;       // list of the group level behind it, nullptr when that does not run
 };
 
 // The half of the plan that allocates nothing: validated parameters, scene and view constants, sizes.
@@ -788,6 +797,8 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     plan->want_mask = p.compaction == MCULL_COMPACT_ORDERED || p.write_mask;
     plan->work = nullptr;
     plan->precull_units = 0;
+    plan->hand_on = false;
+    plan->group_work = nullptr;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
     plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
     plan->two_level = mcull::needs_tile_offsets(s.n_groups);
@@ -873,10 +884,25 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             plan->precull_units = ranged ? s.n_groups : c->n_instances;
             if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
             plan->work = (uint32_t *)o.work.p;
+            // The pre-pass also tells the mask pass which instances need no frustum / no occlusion test (two bits in the
+            // work list's entries) where that arithmetic is what the pass waits for: cache-resident bounds (1 M instances of
+            // one mesh: mask pass 12.2 -> 11.3 ms).  A pass over streamed bounds is bound by its bytes and keeps its constant
+            // tests (100 M pairs with the occlusion test: 0.278 ms without the flags, 0.285 ms with them).
+            plan->hand_on = c->precull_flags && c->n_instances < (1ull << 30) && !plan->streaming;
+            // instances of 32 groups and more: a group level thins the list once more
+            if (plan->hand_on && c->precull_groups && s.n_groups >= 32ull * c->n_instances && s.n_groups < (1ull << 30)) {
+                if (!c->gspheres_valid) {
+                    if ((rc = ensure(c, c->group_spheres, mcull::range_sphere_bytes((uint32_t)c->n_meshlets)))) return rc;
+                    HIPCHK(c, mcull::launch_group_spheres(s.centre_radius, (uint32_t)c->n_meshlets, (float4 *)c->group_spheres.p, c->stream));
+                    c->gspheres_valid = true;
+                }
+                if ((rc = ensure(c, o.group_work, mcull::work_list_bytes(s.n_groups, ranged)))) return rc;
+                plan->group_work = (uint32_t *)o.group_work.p;
+            }
             if (c->precull_adaptive && !o.probe_pending) {
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
                 o.probe_pending = true;
-                o.probe_units = plan->precull_units;
+                o.probe_units = plan->group_work ? s.n_groups : plan->precull_units;
             }
         }
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
@@ -916,6 +942,7 @@ void finish_cull(mcull_ctx::ViewOut &o, const CullPlan &pl, mcull_cull_result *r
     o.last.n_pairs = pl.n_pairs;
     o.last.work = pl.work;
     o.last.precull_units = pl.precull_units;
+    o.last.group_work = pl.group_work;
     if (result) {
         result->list = pl.list;
         result->commands = pl.commands;
@@ -959,11 +986,7 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
                                               (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
-        // The pre-pass also tells the mask pass which instances need no frustum / no occlusion test (two bits in the
-        // work list's entries) where that arithmetic is what the pass waits for: cache-resident bounds (1 M instances of
-        // one mesh: mask pass 12.2 -> 11.3 ms).  A pass over streamed bounds is bound by its bytes and keeps its constant
-        // tests (100 M pairs with the occlusion test: 0.278 ms without the flags, 0.285 ms with them).
-        const bool hand_on = pl.work && c->precull_flags && c->n_instances < (1ull << 30) && !pl.streaming;
+        const bool hand_on = pl.work && pl.hand_on;
         if (pl.work) {
             // the mask pass will cover the work list's groups only: every other ballot is zero from here
             HIPCHK(c, hipMemsetAsync(pl.work, 0, 4, c->stream));
@@ -972,10 +995,15 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
             if (!inline_zero) HIPCHK(c, hipMemsetAsync(o.mask.p, 0, pl.s.n_groups * 8, c->stream));
             HIPCHK(c, mcull::launch_instance_precull(pl.s, (const float4 *)c->range_spheres.p, c->have_ranges,
                                                      c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl.v, view_dev,
-                                                     pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, hand_on, c->stream));
+                                                     pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, hand_on, c->stream,
+                                                     pl.group_work));
+            if (pl.group_work)
+                HIPCHK(c, mcull::launch_group_precull(pl.s, (const float4 *)c->group_spheres.p, (uint32_t)c->n_meshlets, pl.v, view_dev,
+                                                      pl.work, pl.group_work, c->stream));
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
-                                          c->stream, view_dev, pl.work, c->precull_adaptive ? c->kept_dev : nullptr, hand_on));
+                                          c->stream, view_dev, pl.group_work ? pl.group_work : pl.work,
+                                          c->precull_adaptive ? c->kept_dev : nullptr, hand_on, pl.group_work != nullptr));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
@@ -1333,6 +1361,24 @@ int mcull_precull_stats(mcull_ctx *c, uint64_t *instances_or_groups_marked, uint
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t n = o.last.precull_units - kept;
     if (instances_or_groups_marked) *instances_or_groups_marked = n;
+    return MCULL_OK;
+}
+
+int mcull_precull_group_stats(mcull_ctx *c, uint64_t *groups_dropped, uint64_t *groups_tested) {
+    if (!c) return MCULL_E_INVALID;
+    mcull_ctx::ViewOut &o = c->out[c->cur];
+    if (!o.last.valid) return fail(c, MCULL_E_STATE, "no cull result");
+    if (groups_dropped) *groups_dropped = 0;
+    if (groups_tested) *groups_tested = 0;
+    if (!o.last.group_work) return MCULL_OK;  // the group level did not run for this cull
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t listed = 0, kept = 0;  // entries the instance level handed over, groups that survived
+    HIPCHK(c, hipMemcpyAsync(&listed, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&kept, o.last.group_work, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t tested = o.last.scene.group_rec ? (uint64_t)listed : (uint64_t)listed * o.last.scene.groups_per_instance;
+    if (groups_tested) *groups_tested = tested;
+    if (groups_dropped) *groups_dropped = tested - kept;
     return MCULL_OK;
 }
 

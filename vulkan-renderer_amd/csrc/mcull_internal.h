@@ -86,16 +86,22 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
 // host-mapped memory) or nullptr
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr, const uint32_t *work = nullptr,
-                            uint32_t *kept_report = nullptr, bool flags = false);
+                            uint32_t *kept_report = nullptr, bool flags = false, bool list_of_groups = false);
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
 size_t range_sphere_bytes(uint32_t n_ranges);  // what launch_range_spheres writes: n float4 spheres, then n float largest radii
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st);
+// sphere m encloses the meshlets [m, m + 64), hence every 64-meshlet group that starts at meshlet m (range_sphere_bytes(n_meshlets))
+hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st);
 // The single-view pre-pass: `work` = work_list_bytes(...) bytes, first word zeroed by the caller.  zero_mask != nullptr:
 // the pre-pass also zeroes the ballot words of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
-                                   bool want_flags, hipStream_t st);
+                                   bool want_flags, hipStream_t st, uint32_t *next_list = nullptr);
+// The group level: thins the instance level's list `in` (built with want_flags) into `out`, whose first word
+// launch_instance_precull has zeroed (next_list); uniform scenes get one uint32 per group (launch_cull_mask: list_of_groups).
+hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint32_t n_meshlets, const ViewConst &v,
+                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st);
 // The pre-pass of a multi-view cull: one byte per instance and view slot (flags[instance * MCULL_MAX_VIEWS + view]:
 // bit 0 every meshlet rejected, bit 1 none rejected by the frustum test, bit 2 none by the occlusion test);
 // *useful (zeroed by the caller) receives the number of non-zero bytes.
