@@ -398,7 +398,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                               adopt=not args.copy_bounds)
         ctx.upload_transforms(xf.data_ptr(), count=n_inst, mem=mc.MEM_DEVICE)
         ctx.set_instance_ranges(off, cnt)
-        g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=45.0, width=3840, height=2160, flip_y=not args.unflipped)
+        g = env.host.create_globals(eye=(51.0, 54.4, 40.8), fov_deg=args.fov, width=3840, height=2160, flip_y=not args.unflipped)
         use_hiz, hiz_size = args.hiz, (3840, 2160)
         unique = n_inst * per
         if workload == "config5":
@@ -1089,6 +1089,9 @@ def main():
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-precull", action="store_true", help="cull workloads: switch the instance-level pre-cull off")
     ap.add_argument("--tests", type=int, default=None, help="cull workloads, experiments: MCULL_TEST_* bits to run instead of the workload's")
+    ap.add_argument("--fov", type=float, default=45.0,
+                    help="config4/5, experiments: vertical field of view of the camera in degrees (45 = the workload's; a wide one leaves "
+                         "the instance level nothing to drop)")
     ap.add_argument("--exact", action="store_true",
                     help="cull workloads: every pair through the IEEE expressions instead of the guarded fast forms (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

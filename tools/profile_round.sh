@@ -43,6 +43,7 @@ for w in $WHAT; do
       line config4_no_precull --no-precull || exit 1
       line config4_force_dist --force-dist --no-strong-leg || exit 1
       line config3 --workload config3 --steps 20 --warmup 3 || exit 1
+      line config3_random --workload config3 --c3-mesh random --steps 20 --warmup 3 || exit 1
       line config5 --workload config5 --steps 20 --warmup 3 || exit 1
       line hiz --workload hiz || exit 1
       line config1 --workload config1 --graph || exit 1
@@ -53,6 +54,7 @@ for w in $WHAT; do
       trace config4 --steps 50 --warmup 10 || exit 1
       trace config4_hiz_flipped --hiz --steps 50 --warmup 10 || exit 1
       trace config3 --workload config3 --steps 5 --warmup 2 || exit 1
+      trace config3_random --workload config3 --c3-mesh random --steps 5 --warmup 2 || exit 1
       trace config5 --workload config5 --steps 5 --warmup 2 || exit 1
       ;;
     pmc)
