@@ -129,14 +129,36 @@ __device__ __forceinline__ void raster_pixel(const Tri &t, float area, bool tl0,
     atomicMax(dst, bits);
 }
 
-// VP: proj*view is read from a device record written earlier on the stream instead of the kernel
-// arguments (replayable HIP graphs with a moving camera).
+// What a rasteriser call needs before its waves start, in one launch: the depth image cleared to 0 (n_pixels = 0: the
+// caller keeps its contents) and mvp = (proj*view) * model of every instance, element i = 4*c + r summed in the order
+// k = 0..3 (one thread per element).  The rasteriser's waves used to evaluate the matrix per visible meshlet - sixteen
+// lanes, then sixteen broadcasts into SGPRs, about 40 of the 333 vector instructions a meshlet cost - although a scene
+// has hundreds of visible meshlets per instance; they now fetch the sixteen floats of their instance with scalar loads,
+// one iteration ahead.  Taking the place of the clear's memset, it adds no launch to a frame.
+// VP: proj*view is read from a device record written earlier on the stream instead of the kernel arguments
+// (replayable HIP graphs with a moving camera).
 template <bool VP>
+__global__ __launch_bounds__(kRasterBlock) void raster_prepare_kernel(const float *__restrict__ transforms, uint64_t n_elements,
+                                                                     RasterConst rc, const ViewConst *__restrict__ view_dev,
+                                                                     float *__restrict__ mvp, uint32_t *__restrict__ depth_bits,
+                                                                     uint64_t n_pixels) {
+    const uint64_t tid = (uint64_t)blockIdx.x * kRasterBlock + threadIdx.x, stride = (uint64_t)gridDim.x * kRasterBlock;
+    const float *vp = VP ? view_dev->vp : rc.vp;
+    for (uint64_t i = tid; i < n_elements; i += stride) {
+        const uint32_t r = (uint32_t)i & 3u;
+        const float4 col = *reinterpret_cast<const float4 *>(transforms + (i & ~(uint64_t)3));  // column c of the instance's model matrix
+        mvp[i] = ((vp[r] * col.x + vp[4 + r] * col.y) + vp[8 + r] * col.z) + vp[12 + r] * col.w;
+    }
+    const uint64_t n4 = n_pixels / 4;  // the image starts on a 16-byte boundary
+    for (uint64_t i = tid; i < n4; i += stride) reinterpret_cast<uint4 *>(depth_bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < n_pixels - n4 * 4) depth_bits[n4 * 4 + tid] = 0u;
+}
+
 __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     const mcull_visible *__restrict__ list, const unsigned long long *__restrict__ total, uint64_t capacity,
     const mcull_meshlet *__restrict__ meshlets, const uint32_t *__restrict__ meshlet_data,
-    const mcull_vertex *__restrict__ vertices, const float *__restrict__ transforms, RasterConst rc,
-    uint32_t *__restrict__ depth_bits, const ViewConst *__restrict__ view_dev, HugeQueue queue) {
+    const mcull_vertex *__restrict__ vertices, const float *__restrict__ mvp_all, RasterConst rc,
+    uint32_t *__restrict__ depth_bits, HugeQueue queue) {
     const uint32_t lane = threadIdx.x & 63u;
     // the wave index is made provably wave-uniform, so that the list entry, the meshlet header and
     // the matrix are fetched with scalar loads into SGPRs
@@ -163,37 +185,36 @@ __global__ __launch_bounds__(kRasterBlock) void depth_raster_kernel(
     // Software pipeline over the dependent loads entry -> header -> vertex id -> vertex: the entry is
     // fetched three iterations ahead, the header two, the vertex id one, so that an iteration waits
     // for a single memory round trip (the vertex itself) instead of four.  The corner indices of the
-    // triangles (two per lane: a meshlet has at most 124 <= 128) travel with the vertex id.  (One stage
-    // more - position and matrix one iteration ahead - costs 17 registers, drops a wave per SIMD and
-    // measured 7 % slower.)
+    // triangles (two per lane: a meshlet has at most 124 <= 128) travel with the vertex id, and so does the
+    // instance's matrix (instance_mvp_kernel): sixteen scalar registers.  (One stage more - the position one
+    // iteration ahead - costs vector registers, drops a wave per SIMD and measured 7 % slower.)
+    struct Mvp {
+        float m[16];
+    };
+    auto load_mvp = [&](const mcull_visible &en) {
+        const float *src = mvp_all + (size_t)__builtin_amdgcn_readfirstlane(en.drawID) * 16;
+        Mvp r;
+#pragma unroll
+        for (int j = 0; j < 16; j++) r.m[j] = src[j];
+        return r;
+    };
     mcull_visible ent_a = load_entry(wave0), ent_b = load_entry(wave0 + n_waves), ent_c = load_entry(wave0 + 2 * n_waves);
     Hdr hdr_a = load_header(ent_a), hdr_b = load_header(ent_b);
     uint32_t gid_a = load_vertex_id(hdr_a);
     uint32_t cor0_a = load_corners(hdr_a, lane), cor1_a = load_corners(hdr_a, lane + 64u);
+    Mvp mvp_a = load_mvp(ent_a);
     for (uint64_t e = wave0; e < n; e += n_waves) {
         const mcull_visible ent_d = load_entry(e + 3 * n_waves);
         const Hdr hdr_c = load_header(ent_c);
         const uint32_t gid_b = load_vertex_id(hdr_b);
         const uint32_t cor0_b = load_corners(hdr_b, lane), cor1_b = load_corners(hdr_b, lane + 64u);
-        const mcull_visible ent = ent_a;
+        const Mvp cur = mvp_a;
+        const float *mvp = cur.m;
         const uint32_t vc = hdr_a.vc, tc = hdr_a.tc, gid = gid_a, cor0 = cor0_a, cor1 = cor1_a;
         ent_a = ent_b; ent_b = ent_c; ent_c = ent_d;
         hdr_a = hdr_b; hdr_b = hdr_c;
         gid_a = gid_b; cor0_a = cor0_b; cor1_a = cor1_b;
-        // mvp = (proj*view) * model, the element sum in the order k = 0..3: lane i < 16 evaluates element
-        // i = 4*c + r, and the sixteen results are broadcast into SGPRs
-        float mvp[16];
-        {
-            const uint32_t r = lane & 3u, c = (lane >> 2) & 3u;
-            const float4 col = *reinterpret_cast<const float4 *>(transforms + (size_t)ent.drawID * 16 + 4 * c);
-            const float a0 = VP ? view_dev->vp[r] : r == 0 ? rc.vp[0] : r == 1 ? rc.vp[1] : r == 2 ? rc.vp[2] : rc.vp[3];
-            const float a1 = VP ? view_dev->vp[4 + r] : r == 0 ? rc.vp[4] : r == 1 ? rc.vp[5] : r == 2 ? rc.vp[6] : rc.vp[7];
-            const float a2 = VP ? view_dev->vp[8 + r] : r == 0 ? rc.vp[8] : r == 1 ? rc.vp[9] : r == 2 ? rc.vp[10] : rc.vp[11];
-            const float a3 = VP ? view_dev->vp[12 + r] : r == 0 ? rc.vp[12] : r == 1 ? rc.vp[13] : r == 2 ? rc.vp[14] : rc.vp[15];
-            const float el = ((a0 * col.x + a1 * col.y) + a2 * col.z) + a3 * col.w;
-#pragma unroll
-            for (int j = 0; j < 16; j++) mvp[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(el), j));
-        }
+        mvp_a = load_mvp(ent_a);
         // lane l: local vertex l -> clip and screen position
         ClipV cv = {0.0f, 0.0f, 0.0f, 0.0f};
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
@@ -381,8 +402,10 @@ size_t depth_raster_scratch_bytes() { return 256 + sizeof(HugeTri) * kQueueTrian
 
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
-                               const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               void *scratch, hipStream_t st, const ViewConst *view_dev) {
+                               const float *transforms, uint64_t n_instances, float *mvp, const float vp[16], uint32_t w,
+                               uint32_t h, float *depth, bool clear, void *scratch, hipStream_t st, const ViewConst *view_dev) {
+    // mvp: 64 bytes per instance, written here for every instance of the scene (the list's drawIDs index it);
+    // clear: the depth image (w * h floats, 16-byte aligned) is zeroed first
     // scratch: depth_raster_scratch_bytes() of device memory (counters - zero before the first call -, the triangle
     // table, the job queue)
     HugeQueue queue;
@@ -422,18 +445,26 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
         int dev = 0, cus = 256, per_cu = 4;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel<false>, kRasterBlock, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, depth_raster_kernel, kRasterBlock, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         const char *e = std::getenv("MCULL_RASTER_GRID");  // evaluation switch: workgroups in the grid (the image does not depend on it)
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)(cus * per_cu);
     }();
-    if (view_dev)
-        hipLaunchKernelGGL(depth_raster_kernel<true>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
-                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth), view_dev, queue);
-    else
-        hipLaunchKernelGGL(depth_raster_kernel<false>, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total,
-                           capacity, meshlets, meshlet_data, vertices, transforms, rc, reinterpret_cast<uint32_t *>(depth),
-                           (const ViewConst *)nullptr, queue);
+    const uint64_t n_elements = n_instances * 16, n_pixels = clear ? (uint64_t)w * h : 0;
+    if (n_elements || n_pixels) {
+        const uint64_t want = ((n_elements > n_pixels / 16 ? n_elements : n_pixels / 16) + kRasterBlock - 1) / kRasterBlock;  // four 16-byte stores per thread
+        const dim3 prep_grid((uint32_t)(want < 1 ? 1 : want > 8192 ? 8192 : want));
+        if (view_dev)
+            hipLaunchKernelGGL(raster_prepare_kernel<true>, prep_grid, dim3(kRasterBlock), 0, st, transforms, n_elements, rc, view_dev, mvp,
+                               reinterpret_cast<uint32_t *>(depth), n_pixels);
+        else
+            hipLaunchKernelGGL(raster_prepare_kernel<false>, prep_grid, dim3(kRasterBlock), 0, st, transforms, n_elements, rc,
+                               (const ViewConst *)nullptr, mvp, reinterpret_cast<uint32_t *>(depth), n_pixels);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(depth_raster_kernel, dim3(grid), dim3(kRasterBlock), 0, st, list, (const unsigned long long *)total, capacity,
+                       meshlets, meshlet_data, vertices, (const float *)mvp, rc, reinterpret_cast<uint32_t *>(depth), queue);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // a fixed grid of an eighth of the main one: an empty queue (the usual case) costs the same 4.5 us of launch

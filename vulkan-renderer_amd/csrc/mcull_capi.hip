@@ -118,6 +118,7 @@ struct mcull_ctx {
     DevBuf depth_staging, hiz_counter;
     DevBuf depth;  // rasterised depth image (mcull_depth_rasterize)
     DevBuf raster_scratch;  // the rasteriser's queue of huge triangles
+    DevBuf raster_mvp;      // the rasteriser's per-instance (proj*view)*model matrices
     DevBuf view_dev;  // MCULL_MAX_VIEWS + 1 device-resident ViewConst records (the *_device_globals calls; the last one is the rasteriser's)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
@@ -377,7 +378,7 @@ int mcull_destroy(mcull_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->aos, &c->cone, &c->sphere, &c->vertices, &c->mdata, &c->transforms, &c->xf_scale, &c->ranges,
-                      &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->view_flags, &c->depth, &c->view_dev, &c->raster_scratch,
+                      &c->group_base, &c->group_rec, &c->next_nonempty, &c->depth_staging, &c->hiz_counter, &c->view_flags, &c->depth, &c->view_dev, &c->raster_scratch, &c->raster_mvp,
                       &c->range_spheres, &c->group_spheres};
     for (DevBuf *b : bufs) release(*b);
     for (auto &o : c->out)
@@ -1402,7 +1403,7 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     if (int rc = ensure(c, c->depth, bytes)) return rc;
     c->depth_w = width;
     c->depth_h = height;
-    if (clear || resized) HIPCHK(c, hipMemsetAsync(c->depth.p, 0, bytes, c->stream));  // clear value 0 (Engine.cpp:2404)
+    const bool zero_first = clear || resized;  // clear value 0 (Engine.cpp:2404); the rasteriser's first launch does it
     float vp[16];
     const mcull::ViewConst *view_dev = nullptr;
     if (g) {
@@ -1415,6 +1416,7 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
         if (int rc = ensure(c, c->raster_scratch, mcull::depth_raster_scratch_bytes())) return rc;
         HIPCHK(c, hipMemsetAsync(c->raster_scratch.p, 0, 256, c->stream));  // the queue counters; the kernels keep them zero between calls
     }
+    if (int rc = ensure(c, c->raster_mvp, (size_t)(c->n_instances ? c->n_instances : 1) * 64)) return rc;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (view_dev) {
         hipLaunchKernelGGL(derive_view_kernel, dim3(1), dim3(64), 0, c->stream, g_dev, mcull::ViewConst{},
@@ -1423,8 +1425,9 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     }
     HIPCHK(c, mcull::launch_depth_raster(o.last.list, (const uint64_t *)o.total_ptr, o.last.capacity,
                                          (const mcull_meshlet *)c->aos.p, (const uint32_t *)c->mdata.p,
-                                         (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, g ? vp : nullptr,
-                                         width, height, (float *)c->depth.p, c->raster_scratch.p, c->stream, view_dev));
+                                         (const mcull_vertex *)c->vertices.p, (const float *)c->transforms.p, c->n_instances,
+                                         (float *)c->raster_mvp.p, g ? vp : nullptr, width, height, (float *)c->depth.p,
+                                         zero_first, c->raster_scratch.p, c->stream, view_dev));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;

@@ -142,11 +142,12 @@ hipError_t gpu_dedup_vertices(const float *pos, uint64_t npos, const float *nrm,
 hipError_t gpu_build_meshlets(const uint32_t *indices, uint32_t n_tri, std::vector<mcull_meshlet> *meshlets,
                               std::vector<uint32_t> *meshlet_data, hipStream_t st);
 
-// Depth-only software rasteriser over a visible list (depth_kernels.hip); `total` is a device pointer.
+// Depth-only software rasteriser over a visible list (depth_kernels.hip); `total` is a device pointer, `mvp` 64 bytes of
+// device memory per instance (the launch fills it: (proj*view)*model of every instance); clear: zero the image first.
 hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total, uint64_t capacity,
                                const mcull_meshlet *meshlets, const uint32_t *meshlet_data, const mcull_vertex *vertices,
-                               const float *transforms, const float vp[16], uint32_t w, uint32_t h, float *depth,
-                               void *scratch, hipStream_t st, const ViewConst *view_dev = nullptr);
+                               const float *transforms, uint64_t n_instances, float *mvp, const float vp[16], uint32_t w,
+                               uint32_t h, float *depth, bool clear, void *scratch, hipStream_t st, const ViewConst *view_dev = nullptr);
 size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs as `scratch`
 
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero).
