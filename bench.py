@@ -391,6 +391,15 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         n_scene, per = (args.instances or 781250), (args.meshlets_per_instance or 128)
         first, n_inst = shard_range(n_scene, world, rank) if strong else (0, n_scene)
         cone, sphere, xf = make_scene_range(device, first, n_inst, per, seed=42 if strong else 42 + rank)
+        if args.spatial_order:
+            # experiment: the same instances stored cell by cell of a 16^3 grid over the scene (Morton order of the cells),
+            # as a scene graph or a streaming system would store them, instead of in random order
+            cell = ((xf[:, 12:15] + 50.0) * (16.0 / 100.0)).clamp(0, 15).to(torch.int64)
+            key = torch.zeros(n_inst, dtype=torch.int64, device=device)
+            for bit in range(4):
+                for axis in range(3):
+                    key |= ((cell[:, axis] >> bit) & 1) << (3 * bit + axis)
+            xf = xf[torch.argsort(key, stable=True)].contiguous()
         torch.cuda.synchronize()
         off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
         cnt = np.full(n_inst, per, dtype="<u4")
@@ -1089,6 +1098,8 @@ def main():
     ap.add_argument("--gather-lists", action="store_true", help="multi-rank: also time the step with the visible lists all-gathered")
     ap.add_argument("--no-precull", action="store_true", help="cull workloads: switch the instance-level pre-cull off")
     ap.add_argument("--tests", type=int, default=None, help="cull workloads, experiments: MCULL_TEST_* bits to run instead of the workload's")
+    ap.add_argument("--spatial-order", action="store_true",
+                    help="config4/5, experiment: instances stored cell by cell of a 16^3 grid instead of in random order")
     ap.add_argument("--fov", type=float, default=45.0,
                     help="config4/5, experiments: vertical field of view of the camera in degrees (45 = the workload's; a wide one leaves "
                          "the instance level nothing to drop)")
