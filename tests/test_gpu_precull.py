@@ -237,3 +237,54 @@ def test_a_precull_that_removes_nothing_backs_off(mc, O, H, kitten, monkeypatch)
             ran.append(c.precull_stats()[1] > 0)
         first = ran.index(True)
         assert first <= 15 and all(ran[first:]), ran
+
+
+@pytest.mark.parametrize("estimate", [1, 300, 100000])
+def test_grid_sized_for_an_estimate_of_the_list(mc, O, H, kitten, monkeypatch, estimate):
+    """The streaming mask pass sizes its grid for the list length an earlier cull reported and leaves what lies
+    beyond to a second, walking launch: with the estimate forced far too low (1 group), in the middle of the list
+    and above the whole scene, ranged and uniform scenes give the oracle's outputs."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_PRECULL_ADAPTIVE", "0")
+    monkeypatch.setenv("MCULL_FORCE_STREAMING", "1")
+    monkeypatch.setenv("MCULL_PRECULL_ESTIMATE", str(estimate))
+    with mc.Context(0) as c:
+        for k in ("MCULL_PRECULL_MIN_GROUPS", "MCULL_PRECULL_ADAPTIVE", "MCULL_FORCE_STREAMING", "MCULL_PRECULL_ESTIMATE"):
+            monkeypatch.delenv(k)
+        # uniform scene: every instance draws the kitten (6 groups each), entries are instances
+        ml = kitten["meshlets"]
+        n = 400
+        w, h = 640, 480
+        g = H.create_globals(eye=(25.0, 20.0, 18.0), width=w, height=h, meshlet_count=len(ml))
+        t = H.synthetic_transforms(n, extent=30.0, seed=77)
+        depth = H.synthetic_depth(w, h, n_discs=10, seed=3)
+        c.upload_meshlets(ml)
+        c.upload_transforms(t)
+        c.hiz_build(depth, view=0)
+        view = O.View(g, O.hiz_build(depth), w, h)
+        for tests in (7, 3):
+            ref = O.cull_scene(view, t, ml, tests=tests)
+            for _ in range(2):  # the second cull meets the first one's list contents
+                c.cull(g, tests=tests, write_mask=True)
+                compare(mc, c, ref, n)
+            marked, tested, per_group = c.precull_stats()
+            assert tested == n and 0 < marked < n
+        # ranged scene: ragged and empty ranges, entries are groups with their records
+        rs = np.random.RandomState(4)
+        n_inst, per = 300, 200
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=8)
+        t2 = H.synthetic_transforms(n_inst, extent=30.0, seed=9)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = rs.randint(0, per + 1, n_inst).astype("<u4")
+        cnt[3], cnt[4], cnt[200] = 0, 1, 65
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t2)
+        c.set_instance_ranges(off, cnt)
+        g2 = H.create_globals(eye=(40.0, 35.0, 30.0), width=w, height=h)
+        view2 = O.View(g2, O.hiz_build(depth), w, h)
+        for tests in (7, 1):
+            ref = O.cull_scene(view2, t2, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=tests)
+            c.cull(g2, tests=tests, write_mask=True)
+            compare(mc, c, ref, n_inst)
+            marked, tested, per_group = c.precull_stats()
+            assert per_group and 0 < marked < tested

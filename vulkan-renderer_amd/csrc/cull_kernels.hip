@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewConst v_arg,
     uint64_t *__restrict__ mask, uint32_t *__restrict__ tile_counts, uint32_t xcd_contiguous,
     const ViewConst *__restrict__ view_dev, const uint32_t *__restrict__ work, uint32_t *__restrict__ kept_report,
-    uint32_t list_of_groups) {
+    uint32_t list_of_groups, uint32_t start_block) {
     const ViewConst &v = VP ? *view_dev : v_arg;
     const uint32_t tests = (VP || FLAGS) ? v.tests : TESTS;
     // FLAGS only: the list of a scene without per-instance ranges holds one entry per group (group_precull_kernel), not
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     // loop's body exactly once.
     uint32_t n_list = 0;
     if constexpr (FLAGS) n_list = (group_rec || per_group) ? work[0] : work[0] * groups_per_instance;
-    for (uint32_t b = FLAGS ? blockIdx.x : first_block;; b += gridDim.x) {
+    for (uint32_t b = FLAGS ? start_block + blockIdx.x : first_block;; b += gridDim.x) {  // start_block: the walk begins there (FLAGS)
     if (FLAGS && (unsigned long long)b * kGroups >= n_list) break;
     const uint32_t block_g0 = b * kGroups;
     // With a work list (instance_precull_kernel) the pass runs over the list's groups only: the grid is
@@ -1790,51 +1790,76 @@ uint32_t tile_count_for(uint64_t n_groups) { return (uint32_t)((n_groups + kTile
 // above 1024 tiles (16.8 M pairs) the scan launch pays for itself
 bool needs_tile_offsets(uint64_t n_groups) { return tile_count_for(n_groups) > kScanMinTiles; }
 
+// est_groups (0 = unknown; only with a work list and without `flags`): how many groups the list is expected to hold - what
+// an earlier cull of the slot reported, plus a margin.  The grid of the streaming form is then sized for that instead of
+// for the whole scene, and a second, small launch of the walking form takes whatever the list holds beyond it, so the
+// result does not depend on the estimate.  A grid sized for the scene starts a workgroup per 16 groups of the SCENE, and
+// those behind the list's end - a third of them for the 100 M-pair scene, six in seven with its occlusion test on - start,
+// wait for the list's length and leave, as a tail during which nothing else runs.
 template <int NG, bool NT>
 static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                                const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report, bool flags, bool list_of_groups,
-                               hipStream_t st) {
+                               uint64_t est_groups, hipStream_t st) {
     const uint32_t per_block = kWaves * NG;
     const uint32_t log = (flags && work && list_of_groups && !s.group_rec) ? 1u : 0u;
-    const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
+    uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
     if (flags && work) {
         const uint32_t walkers = grid < 16384u ? grid : 16384u;  // the FLAGS form walks the list with a stride
         if (view_dev)
             hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true, true>), dim3(walkers), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                                s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                               tile_counts, 0u, view_dev, work, kept_report, log);
+                               tile_counts, 0u, view_dev, work, kept_report, log, 0u);
         else
             hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, false, true>), dim3(walkers), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                                s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                               tile_counts, 0u, (const ViewConst *)nullptr, work, kept_report, log);
+                               tile_counts, 0u, (const ViewConst *)nullptr, work, kept_report, log, 0u);
         return;
+    }
+    uint32_t tail_from = 0, tail_grid = 0;
+    if (work && est_groups) {
+        const uint64_t est_blocks = (est_groups + per_block - 1) / per_block;  // the caller has added its margin
+        if (est_blocks < grid) {
+            tail_from = (uint32_t)est_blocks;
+            tail_grid = grid - tail_from < 1024u ? grid - tail_from : 1024u;
+            grid = tail_from;
+        }
     }
     if (view_dev) {
         hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius,
                            s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
-                           tile_counts, 0u, view_dev, work, kept_report, 0u);
+                           tile_counts, 0u, view_dev, work, kept_report, 0u, 0u);
+        if (tail_grid)
+            hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, true, true>), dim3(tail_grid), dim3(kBlock), 0, st, s.cone_axis_w,
+                               s.centre_radius, s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v,
+                               mask, tile_counts, 0u, view_dev, work, (uint32_t *)nullptr, 0u, tail_from);
         return;
     }
     MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
                                                      s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
                                                      s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
-                                                     (const ViewConst *)nullptr, work, kept_report, 0u));
+                                                     (const ViewConst *)nullptr, work, kept_report, 0u, 0u));
+    if (tail_grid)
+        hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, false, true>), dim3(tail_grid), dim3(kBlock), 0, st, s.cone_axis_w,
+                           s.centre_radius, s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
+                           tile_counts, 0u, (const ViewConst *)nullptr, work, (uint32_t *)nullptr, 0u, tail_from);
 }
 
 // view_dev != nullptr: the kernels take the view constants (and the tests) from that device record
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev, const uint32_t *work, uint32_t *kept_report,
-                            bool flags, bool list_of_groups) {
+                            bool flags, bool list_of_groups, uint64_t est_groups) {
     // groups per wave: more requests in flight per wave for big scenes, enough workgroups to fill
     // 256 CUs for small ones
+#define MCULL_MASK_T(NG_, NT_) launch_cull_mask_t<NG_, NT_>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, est_groups, st)
     if (streaming) {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
-        else launch_cull_mask_t<2, true>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
+        if (s.n_groups >= (1u << 16)) MCULL_MASK_T(4, true);
+        else MCULL_MASK_T(2, true);
     } else {
-        if (s.n_groups >= (1u << 16)) launch_cull_mask_t<4, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
-        else if (s.n_groups >= (1u << 14)) launch_cull_mask_t<2, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
-        else launch_cull_mask_t<1, false>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, st);
+        if (s.n_groups >= (1u << 16)) MCULL_MASK_T(4, false);
+        else if (s.n_groups >= (1u << 14)) MCULL_MASK_T(2, false);
+        else MCULL_MASK_T(1, false);
     }
+#undef MCULL_MASK_T
     return hipGetLastError();
 }
 

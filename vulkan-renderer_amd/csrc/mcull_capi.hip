@@ -104,6 +104,7 @@ struct mcull_ctx {
     DevBuf group_spheres;
     bool gspheres_valid = false;
     bool precull_groups = true;  // MCULL_PRECULL_GROUPS=0: no group level (measurements)
+    long long precull_estimate = -1;  // MCULL_PRECULL_ESTIMATE=n: the work list is taken to hold n groups (0: no estimate) instead of what the last cull reported (tests)
     // A pre-cull that removes next to nothing costs its own pass and a slower mask pass (100 M pairs, all in
     // view: 0.77 against 0.69 ms).  Each single-view cull that runs it leaves the number of units it kept in
     // host-mapped memory (kept_host[slot], read later without waiting); when that was more than 90 % of the
@@ -164,6 +165,11 @@ struct mcull_ctx {
         bool probe_pending = false;     // a pre-cull ran and its kept count has not been looked at yet
         uint64_t probe_units = 0;
         uint32_t precull_cooldown = 0;  // culls still to go without the pre-cull
+        // what the work list of the slot's last finished pre-culled cull held, in groups (0 = unknown): the streaming
+        // mask pass sizes its grid for it (launch_cull_mask)
+        bool probe_in_groups = false, probe_group_level = false;
+        uint32_t probe_groups_per_instance = 0;
+        uint64_t list_estimate = 0;
     } out[MCULL_MAX_VIEWS];
     uint32_t cur = 0;
 };
@@ -350,6 +356,7 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     if (const char *hs = std::getenv("MCULL_HIZ_STRIPS")) c->hiz_strips = hs[0] != '0';
     if (const char *pf = std::getenv("MCULL_PRECULL_FLAGS")) c->precull_flags = pf[0] != '0';
     if (const char *pg = std::getenv("MCULL_PRECULL_GROUPS")) c->precull_groups = pg[0] != '0';
+    if (const char *pe = std::getenv("MCULL_PRECULL_ESTIMATE")) c->precull_estimate = std::atoll(pe);
     const char *tiles = std::getenv("MCULL_HIZ_TILES"), *streamed = std::getenv("MCULL_HIZ_STREAM");
     const char *single = std::getenv("MCULL_HIZ_SINGLE_LAUNCH");
     const char *fs = std::getenv("MCULL_FORCE_STREAMING");
@@ -723,6 +730,7 @@ struct CullPlan {
     uint64_t precull_units;     // groups (ranged scenes) or instances it decides about
     bool hand_on;               // the list's entries carry what the instance level has settled (cull_mask_kernel<..., FLAGS>)
     uint32_t *group_work;       // list of the group level behind it, nullptr when that does not run
+    uint64_t list_estimate;     // groups the work list is expected to hold (0 = unknown), see launch_cull_mask
 };
 
 // The half of the plan that allocates nothing: validated parameters, scene and view constants, sizes.
@@ -800,6 +808,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     plan->precull_units = 0;
     plan->hand_on = false;
     plan->group_work = nullptr;
+    plan->list_estimate = 0;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
     plan->lay = mcull::CmdLayout{p.cmd_stride, p.cmd_offset, p.cmd_form};
     plan->two_level = mcull::needs_tile_offsets(s.n_groups);
@@ -871,6 +880,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 if (kept != 0xffffffffu) {  // the cull that ran it has finished
                     o.probe_pending = false;
                     if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown = kPrecullCooldown;
+                    o.list_estimate = o.probe_group_level ? 0 : o.probe_in_groups ? (uint64_t)kept : (uint64_t)kept * o.probe_groups_per_instance;
                 }
             }
             if (o.precull_cooldown) {
@@ -904,6 +914,16 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
                 o.probe_pending = true;
                 o.probe_units = plan->group_work ? s.n_groups : plan->precull_units;
+                o.probe_group_level = plan->group_work != nullptr;
+                o.probe_in_groups = ranged;
+                o.probe_groups_per_instance = s.groups_per_instance;
+            }
+            // the walking form that takes what lies beyond the estimate reads two flag bits off the top of an entry
+            if (!plan->hand_on && (ranged || c->n_instances < (1ull << 30))) {
+                // 3 % and 1 024 groups of margin on what was reported; not worth a second launch unless it spares 4 096 groups' workgroups
+                const uint64_t padded = o.list_estimate + o.list_estimate / 32 + 1024;
+                plan->list_estimate = c->precull_estimate >= 0 ? (uint64_t)c->precull_estimate
+                                      : (c->precull_adaptive && o.list_estimate && padded + 4096 < s.n_groups) ? padded : 0;
             }
         }
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
@@ -1004,7 +1024,8 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
                                           c->stream, view_dev, pl.group_work ? pl.group_work : pl.work,
-                                          c->precull_adaptive ? c->kept_dev : nullptr, hand_on, pl.group_work != nullptr));
+                                          c->precull_adaptive ? c->kept_dev : nullptr, hand_on, pl.group_work != nullptr,
+                                          pl.work && !hand_on ? pl.list_estimate : 0));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
         HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));

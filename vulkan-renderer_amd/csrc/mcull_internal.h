@@ -86,7 +86,8 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
 // host-mapped memory) or nullptr
 hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mask, uint32_t *tile_counts,
                             bool streaming, hipStream_t st, const ViewConst *view_dev = nullptr, const uint32_t *work = nullptr,
-                            uint32_t *kept_report = nullptr, bool flags = false, bool list_of_groups = false);
+                            uint32_t *kept_report = nullptr, bool flags = false, bool list_of_groups = false,
+                            uint64_t est_groups = 0);  // est_groups: see launch_cull_mask_t (0 = unknown)
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
 size_t range_sphere_bytes(uint32_t n_ranges);  // what launch_range_spheres writes: n float4 spheres, then n float largest radii
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
