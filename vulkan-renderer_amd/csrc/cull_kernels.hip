@@ -512,9 +512,10 @@ __device__ __forceinline__ void store_entry(mcull_visible *__restrict__ list, un
     else reinterpret_cast<unsigned long long *>(list)[slot] = e;
 }
 
-// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive
+// exclusive scan of one value per thread over a workgroup of WAVES waves; returns the exclusive
 // prefix and writes the workgroup total to *total_out (uniform).
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s_wave /*[kWaves]*/, uint32_t *total_out) {
+template <int WAVES = kWaves>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s_wave /*[WAVES]*/, uint32_t *total_out) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = x;
 #pragma unroll
@@ -526,7 +527,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
     __syncthreads();
     uint32_t wave_base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; w++) {
+    for (int w = 0; w < WAVES; w++) {
         const uint32_t t = s_wave[w];
         if ((uint32_t)w < wave) wave_base += t;
         total += t;
@@ -620,13 +621,14 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
 }
 
 constexpr uint32_t kWorkHeader = 64;  // uint32 words in front of a work list: [0] = number of entries (256-byte header)
-// Instances per thread of the pre-pass (one list reservation per kBlock * items instances).  Every workgroup's
-// reservation is a returning atomic on the same word, and one word takes about 90 of them per microsecond: with the
-// frustum test alone (little arithmetic per instance) 1 526 reservations for 781 250 instances were half of the pass,
-// and 8 instances per thread make the step 5 us shorter (0.531 -> 0.525 ms).  With the occlusion test the threads wait
-// for their texels instead, and more of them in flight is worth more than fewer reservations (100 M pairs against a
-// 4K pyramid: 0.250 ms with 2 per thread, 0.265 ms with 8).
-constexpr int kPreItemsHiz = 2, kPreItemsNoHiz = 8;
+// Shape of the pre-pass: one instance per thread, 1 024 threads per workgroup, one list reservation per workgroup.
+// Every reservation is a returning atomic on the same word, and one word takes about 90 of them per microsecond, so few
+// of them are wanted - but not at the price of few waves: 256 threads with 2 / 8 instances each (1 526 / 381 reservations
+// for 781 250 instances) gave 0.531 / 0.525 ms per step with the frustum test alone and 0.250 / 0.265 ms with the occlusion
+// test, whose threads wait for texels and want many waves in flight; 1 024 threads with one instance each (763
+// reservations, four times the waves) gives 0.517 and 0.229 ms (2 or 4 instances per thread at 1 024, and 512 threads:
+// 0.518 - 0.524 / 0.229 - 0.244 ms).
+constexpr int kPreItems = 1, kPreBlock = 1024;
 
 // Layout of a work list over `units` entries: header, then `units` uint32 (ranged scenes: the group's index
 // in the scene; uniform scenes: the surviving instance's index), then - ranged scenes only - `units` uint4
@@ -848,8 +850,7 @@ __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__
 // on the order.  It never starts on a group that is not in the list: the ballots of those groups are zeroed
 // here (zero_mask; scenes with few groups per instance) or by a memset beforehand.
 // The multi-view pass has its own form of this level (classify_views_kernel): no list, one byte per instance and view.
-template <int kPreItems>
-__global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *__restrict__ transforms,
+__global__ __launch_bounds__(kPreBlock) void instance_precull_kernel(const float4 *__restrict__ transforms,
                                                                   const float4 *__restrict__ spheres, uint32_t per_instance_sphere,
                                                                   const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ group_base, uint32_t n_instances,
@@ -858,10 +859,10 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
                                                                   uint32_t *__restrict__ work, uint64_t *__restrict__ zero_mask,
                                                                   uint32_t want_flags, uint32_t *__restrict__ next_list) {
     const ViewConst &v = view_dev ? *view_dev : v_arg;
-    __shared__ uint32_t s_wave[kWaves];
+    __shared__ uint32_t s_wave[kPreBlock / 64];
     __shared__ uint32_t s_base;
     if (next_list && blockIdx.x == 0 && threadIdx.x == 0) next_list[0] = 0u;  // the group level's list starts empty
-    const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
+    const uint32_t i0 = (blockIdx.x * kPreBlock + threadIdx.x) * kPreItems;  // this thread's kPreItems consecutive instances
     bool outside[kPreItems];
     uint32_t hand_on[kPreItems];  // kInstInside / kInstOpen in bits 30 and 31 of the survivor's list entries (want_flags)
 #pragma unroll
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void instance_precull_kernel(const float4 *
         mine += n[q];
     }
     uint32_t total;
-    const uint32_t excl = block_exclusive_scan(mine, s_wave, &total);
+    const uint32_t excl = block_exclusive_scan<kPreBlock / 64>(mine, s_wave, &total);
     if (threadIdx.x == 0) s_base = total ? atomicAdd(&work[0], total) : 0u;
     __syncthreads();
     uint32_t pos = s_base + excl;
@@ -2052,11 +2053,8 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
                                    bool want_flags, hipStream_t st, uint32_t *next_list) {
     if (s.n_instances == 0) return hipSuccess;
     const float *rmax = reinterpret_cast<const float *>(spheres + (per_instance_sphere ? s.n_instances : 1u));
-    // view_dev: the tests are device data, so the form that suits the occlusion test is taken
-    const bool few = view_dev == nullptr && !(v.tests & MCULL_TEST_HIZ);
-    const uint32_t per_block = kBlock * (few ? kPreItemsNoHiz : kPreItemsHiz);
-    auto kernel = few ? instance_precull_kernel<kPreItemsNoHiz> : instance_precull_kernel<kPreItemsHiz>;
-    hipLaunchKernelGGL(kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kBlock), 0, st, s.transforms,
+    const uint32_t per_block = kPreBlock * kPreItems;
+    hipLaunchKernelGGL(instance_precull_kernel, dim3((s.n_instances + per_block - 1) / per_block), dim3(kPreBlock), 0, st, s.transforms,
                        spheres, per_instance_sphere ? 1u : 0u, s.ranges, group_base, s.n_instances, s.groups_per_instance,
                        group_base ? s.n_groups : (uint64_t)s.n_instances, v, view_dev, rmax, work, zero_mask, want_flags ? 1u : 0u, next_list);
     return hipGetLastError();
