@@ -56,6 +56,9 @@ for w in $WHAT; do
       trace config3 --workload config3 --steps 5 --warmup 2 || exit 1
       trace config3_random --workload config3 --c3-mesh random --steps 5 --warmup 2 || exit 1
       trace config5 --workload config5 --steps 5 --warmup 2 || exit 1
+      trace hiz --workload hiz --steps 50 --warmup 10 || exit 1
+      trace depth --workload depth --steps 50 --warmup 10 || exit 1
+      trace config1 --workload config1 --steps 50 --warmup 10 || exit 1
       ;;
     pmc)
       pmc config4 || exit 1
