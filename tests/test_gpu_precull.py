@@ -269,6 +269,14 @@ def test_grid_sized_for_an_estimate_of_the_list(mc, O, H, kitten, monkeypatch, e
                 compare(mc, c, ref, n)
             marked, tested, per_group = c.precull_stats()
             assert tested == n and 0 < marked < n
+            # the same with the Globals read on the device (the kernels that take their view constants from memory)
+            import torch
+
+            g_dev = torch.from_numpy(np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1).view("u1").reshape(-1).copy()).to("cuda:0")
+            torch.cuda.synchronize()
+            c.cull_device_globals(g_dev.data_ptr(), len(ml), tests=tests, write_mask=True)
+            compare(mc, c, ref, n)
+            assert c.precull_stats()[0] == marked
         # ranged scene: ragged and empty ranges, entries are groups with their records
         rs = np.random.RandomState(4)
         n_inst, per = 300, 200
