@@ -1853,7 +1853,10 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
     // 256 CUs for small ones
 #define MCULL_MASK_T(NG_, NT_) launch_cull_mask_t<NG_, NT_>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, est_groups, st)
     if (streaming) {
-        if (s.n_groups >= (1u << 16)) MCULL_MASK_T(4, true);
+        // a work list expected to be short is spread over twice as many waves: 211 000 listed groups of the 100 M-pair
+        // scene with its occlusion test on, 0.230 -> 0.221 ms per step (the 1.06 M groups listed without it: four per wave)
+        const bool short_list = work && !flags && est_groups && est_groups < (1u << 18);
+        if (s.n_groups >= (1u << 16) && !short_list) MCULL_MASK_T(4, true);
         else MCULL_MASK_T(2, true);
     } else {
         if (s.n_groups >= (1u << 16)) MCULL_MASK_T(4, false);
