@@ -219,3 +219,37 @@ def test_the_switch_takes_the_level_away(mc, O, H, monkeypatch):
         c.cull(g, tests=7, write_mask=True)
         compare(mc, c, ref, n_inst)
         assert c.precull_group_stats() == (0, 0) and c.precull_stats()[1] == n_inst
+
+
+def test_a_group_level_that_removes_nothing_backs_off(mc, O, H, monkeypatch):
+    """A group level that hands on (nearly) everything it was given costs its pass for nothing: after a cull that
+    reported so it is left out for a while - the instance level stays - and the outputs are the same either way."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    with mc.Context(0) as c:
+        monkeypatch.delenv("MCULL_PRECULL_MIN_GROUPS")
+        n_inst, per = 48, 64 * 40
+        # a compact mesh (unrelated meshlets in a unit cube: a group's sphere is the instance's) drawn half in front of
+        # the camera and half behind it: the instance level removes the half behind, the group level nothing
+        cone, sphere = H.synthetic_bounds(per, seed=3)
+        t = H.synthetic_transforms(n_inst, extent=4.0, seed=21)
+        m = t["model"].reshape(n_inst, 4, 4).copy()
+        m[: n_inst // 2, 3, :3] += np.float32(200.0)  # far behind the camera at (20, 20, 20) looking at the origin
+        t["model"] = m.reshape(n_inst, 16)
+        w, h = 640, 480
+        g = H.create_globals(eye=(20.0, 20.0, 20.0), width=w, height=h, meshlet_count=per)
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        ref = O.cull_scene(O.View(g, None, w, h), t, cone_axis_w=cone, centre_radius=sphere, tests=3)
+        ran, skipped = 0, 0
+        for k in range(6):
+            c.cull(g, tests=3, write_mask=True)
+            compare(mc, c, ref, n_inst)  # (the downloads wait for the cull, so the next one sees its report)
+            marked = c.precull_stats()[0]
+            assert marked >= n_inst // 2, "the instance level keeps running"
+            dropped, tested = c.precull_group_stats()
+            if tested:
+                ran += 1
+                assert dropped * 10 < tested, "the scene is built so that the group level finds next to nothing"
+            else:
+                skipped += 1
+        assert ran >= 1 and skipped >= 3, (ran, skipped)

@@ -930,11 +930,15 @@ __global__ __launch_bounds__(kBlock) void group_precull_kernel(const float4 *__r
                                                                const float4 *__restrict__ gspheres, const float *__restrict__ grmax,
                                                                uint32_t groups_per_instance, uint64_t units, ViewConst v_arg,
                                                                const ViewConst *__restrict__ view_dev,
-                                                               const uint32_t *__restrict__ in, uint32_t *__restrict__ out) {
+                                                               const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                               uint32_t *__restrict__ in_report) {
     const ViewConst &v = view_dev ? *view_dev : v_arg;
     __shared__ uint32_t s_wave[kWaves];
     __shared__ uint32_t s_base;
     const uint32_t n_in = RANGED ? in[0] : in[0] * groups_per_instance;
+    // how many groups this level was handed, left where the host can look at it later without waiting (host-mapped
+    // memory): with what the mask pass reports of the list it got, that says whether this level earns its time
+    if (in_report && blockIdx.x == 0 && threadIdx.x == 0) *in_report = n_in;
     const uint4 *in_rec = reinterpret_cast<const uint4 *>(in + work_rec_offset_words(units));
     uint4 *out_rec = reinterpret_cast<uint4 *>(out + work_rec_offset_words(units));
     constexpr uint32_t kPerBlock = kBlock * kGrpItems;
@@ -2067,7 +2071,7 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
 // want_flags), `out` = work_list_bytes(n_groups, ranged) bytes whose first word is zero by then (next_list above);
 // gspheres = what launch_group_spheres wrote for the n_meshlets uploaded.
 hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint32_t n_meshlets, const ViewConst &v,
-                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st) {
+                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st, uint32_t *in_report) {
     if (s.n_groups == 0) return hipSuccess;
     const bool ranged = s.group_rec != nullptr;
     const float *grmax = reinterpret_cast<const float *>(gspheres + n_meshlets);
@@ -2075,10 +2079,10 @@ hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint3
     const uint32_t walkers = blocks < 4096u ? (uint32_t)blocks : 4096u;
     if (ranged)
         hipLaunchKernelGGL(group_precull_kernel<true>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
-                           s.groups_per_instance, s.n_groups, v, view_dev, in, out);
+                           s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
     else
         hipLaunchKernelGGL(group_precull_kernel<false>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
-                           s.groups_per_instance, s.n_groups, v, view_dev, in, out);
+                           s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
     return hipGetLastError();
 }
 

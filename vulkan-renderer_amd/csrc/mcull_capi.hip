@@ -109,8 +109,11 @@ struct mcull_ctx {
     // view: 0.77 against 0.69 ms).  Each single-view cull that runs it leaves the number of units it kept in
     // host-mapped memory (kept_host[slot], read later without waiting); when that was more than 90 % of the
     // units, the following kPrecullCooldown culls of the slot go without, then it is tried again.
+    // The group level behind it is judged the same way on its own: it reports how many groups it was handed
+    // (kept_host[2]), and when more than 90 % of them were still in the list the mask pass got, the following
+    // kPrecullCooldown culls run the instance level alone.
     // MCULL_PRECULL_ADAPTIVE=0 switches the back-off off (tests that look at the pre-cull's statistics).
-    volatile uint32_t *kept_host = nullptr;  // MCULL_MAX_VIEWS words, hipHostMalloc (mapped)
+    volatile uint32_t *kept_host = nullptr;  // MCULL_MAX_VIEWS words, hipHostMalloc (mapped): [0] single-view culls, [1] multi-view, [2] group level
     uint32_t *kept_dev = nullptr;            // the same memory as the device sees it
     bool precull_adaptive = true;
 
@@ -165,6 +168,7 @@ struct mcull_ctx {
         bool probe_pending = false;     // a pre-cull ran and its kept count has not been looked at yet
         uint64_t probe_units = 0;
         uint32_t precull_cooldown = 0;  // culls still to go without the pre-cull
+        uint32_t group_cooldown = 0;    // culls still to go without the group level (it removed less than a tenth of what it was handed)
         // what the work list of the slot's last finished pre-culled cull held, in groups (0 = unknown): the streaming
         // mask pass sizes its grid for it (launch_cull_mask)
         bool probe_in_groups = false, probe_group_level = false;
@@ -881,6 +885,10 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                     o.probe_pending = false;
                     if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown = kPrecullCooldown;
                     o.list_estimate = o.probe_group_level ? 0 : o.probe_in_groups ? (uint64_t)kept : (uint64_t)kept * o.probe_groups_per_instance;
+                    // the group level: what it kept (the mask pass's list) against what it was handed (kept_host[2])
+                    const uint32_t handed = c->kept_host[2];
+                    if (o.probe_group_level && handed != 0xffffffffu && (uint64_t)kept * 10 > (uint64_t)handed * 9)
+                        o.group_cooldown = kPrecullCooldown;
                 }
             }
             if (o.precull_cooldown) {
@@ -901,7 +909,10 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             // tests (100 M pairs with the occlusion test: 0.278 ms without the flags, 0.285 ms with them).
             plan->hand_on = c->precull_flags && c->n_instances < (1ull << 30) && !plan->streaming;
             // instances of 32 groups and more: a group level thins the list once more
-            if (plan->hand_on && c->precull_groups && s.n_groups >= 32ull * c->n_instances && s.n_groups < (1ull << 30)) {
+            const bool group_level = plan->hand_on && c->precull_groups && s.n_groups >= 32ull * c->n_instances && s.n_groups < (1ull << 30);
+            if (group_level && c->precull_adaptive && o.group_cooldown) {
+                o.group_cooldown--;
+            } else if (group_level) {
                 if (!c->gspheres_valid) {
                     if ((rc = ensure(c, c->group_spheres, mcull::range_sphere_bytes((uint32_t)c->n_meshlets)))) return rc;
                     HIPCHK(c, mcull::launch_group_spheres(s.centre_radius, (uint32_t)c->n_meshlets, (float4 *)c->group_spheres.p, c->stream));
@@ -912,6 +923,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             }
             if (c->precull_adaptive && !o.probe_pending) {
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
+                if (plan->group_work) c->kept_host[2] = 0xffffffffu;       // and its group level (single-view culls are slot 0)
                 o.probe_pending = true;
                 o.probe_units = plan->group_work ? s.n_groups : plan->precull_units;
                 o.probe_group_level = plan->group_work != nullptr;
@@ -1020,7 +1032,7 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
                                                      pl.group_work));
             if (pl.group_work)
                 HIPCHK(c, mcull::launch_group_precull(pl.s, (const float4 *)c->group_spheres.p, (uint32_t)c->n_meshlets, pl.v, view_dev,
-                                                      pl.work, pl.group_work, c->stream));
+                                                      pl.work, pl.group_work, c->stream, c->precull_adaptive ? c->kept_dev + 2 : nullptr));
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
                                           c->stream, view_dev, pl.group_work ? pl.group_work : pl.work,

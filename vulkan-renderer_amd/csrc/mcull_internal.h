@@ -102,7 +102,8 @@ hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, boo
 // The group level: thins the instance level's list `in` (built with want_flags) into `out`, whose first word
 // launch_instance_precull has zeroed (next_list); uniform scenes get one uint32 per group (launch_cull_mask: list_of_groups).
 hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint32_t n_meshlets, const ViewConst &v,
-                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st);
+                                const ViewConst *view_dev, const uint32_t *in, uint32_t *out, hipStream_t st,
+                                uint32_t *in_report = nullptr)  /* in_report: receives the number of groups handed in (host-mapped memory) */;
 // The pre-pass of a multi-view cull: one byte per instance and view slot (flags[instance * MCULL_MAX_VIEWS + view]:
 // bit 0 every meshlet rejected, bit 1 none rejected by the frustum test, bit 2 none by the occlusion test);
 // *useful (zeroed by the caller) receives the number of non-zero bytes.
