@@ -18,7 +18,8 @@ def usage(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not found")
     out = tmp_path_factory.mktemp("res") / "cull.o"
-    run = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "--cuda-device-only",
+    # the flags of the library's build (csrc/Makefile: the cull kernels are built without the SLP vectoriser)
+    run = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only",
                           "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", str(out)],
                          check=True, capture_output=True, text=True, timeout=900)
     kernels, name = {}, None
