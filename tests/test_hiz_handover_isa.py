@@ -21,7 +21,7 @@ def kernels(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not found")
     out = tmp_path_factory.mktemp("isa") / "hiz.s"
-    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "--cuda-device-only", "-S", SRC,
+    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "--cuda-device-only", "-S", SRC,
                     "-o", str(out)], check=True, capture_output=True, timeout=600)
     lines = out.read_text().split("\n")
     found = {}
