@@ -1013,7 +1013,12 @@ __global__ __launch_bounds__(kBlock) void group_precull_kernel(const float4 *__r
 // FLAGS: the work list's entries carry kInstInside / kInstOpen in bits 30 and 31 (the pre-pass was asked for them):
 // the groups of such an instance run without the frustum / occlusion test.  The tests are then a run-time value
 // (v.tests, as with VP), narrowed per group.
-template <uint32_t TESTS, int NG, bool NT, bool VP = false, bool FLAGS = false>
+// PK (streamed bounds only): two groups per step on packed operations (pair_visible2_impl) - or, PK = false, one group
+// per step like the cache-resident form.  The packed step skips a test only when neither of its groups needs it, which
+// costs more than the halved multiply/add count saves when the groups come from a work list without the occlusion test
+// (three in four of their pairs are visible; 100 M pairs 0.516 -> 0.509 ms); the whole scene (0.575 against 0.592 ms)
+// and lists with the occlusion test (0.219 against 0.225 ms) keep the packed step.
+template <uint32_t TESTS, int NG, bool NT, bool VP = false, bool FLAGS = false, bool PK = true>
 __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
@@ -1127,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
             s_pop[slot] = (uint32_t)__popcll(ballot);
         }
     };
-    if constexpr (NG % 2 == 0 && NT) {
+    if constexpr (NG % 2 == 0 && NT && PK) {
 #pragma unroll
         for (int k = 0; k < NG; k += 2) {  // two groups per step: one pair per vector element
             const uint32_t slot = wave * NG + k;
@@ -1839,10 +1844,21 @@ static void launch_cull_mask_t(const SceneDev &s, const ViewConst &v, uint64_t *
                                mask, tile_counts, 0u, view_dev, work, (uint32_t *)nullptr, 0u, tail_from);
         return;
     }
-    MCULL_DISPATCH_TESTS(v.tests, hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st,
-                                                     s.cone_axis_w, s.centre_radius, s.transforms, s.xf_scale, s.group_rec,
-                                                     s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
-                                                     (const ViewConst *)nullptr, work, kept_report, 0u, 0u));
+    // streamed bounds behind a work list, no occlusion test: the one-group step (see PK)
+    const bool scalar_step = NT && work != nullptr && !(v.tests & MCULL_TEST_HIZ);
+    MCULL_DISPATCH_TESTS(v.tests, {
+        if constexpr (NT && (T & MCULL_TEST_HIZ) == 0u) {
+            if (scalar_step) {
+                hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT, false, false, false>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w,
+                                   s.centre_radius, s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v,
+                                   mask, tile_counts, 0u, (const ViewConst *)nullptr, work, kept_report, 0u, 0u);
+                break;
+            }
+        }
+        hipLaunchKernelGGL((cull_mask_kernel<T, NG, NT>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, s.transforms,
+                           s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask, tile_counts, 0u,
+                           (const ViewConst *)nullptr, work, kept_report, 0u, 0u);
+    });
     if (tail_grid)
         hipLaunchKernelGGL((cull_mask_kernel<7u, NG, NT, false, true>), dim3(tail_grid), dim3(kBlock), 0, st, s.cone_axis_w,
                            s.centre_radius, s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, v, mask,
