@@ -1276,65 +1276,33 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     // what does not depend on the view is evaluated once per group: the transforms, the world-space
     // centre and radius, and the unit cone axis (for pairs no view tests with the cone that is wasted
     // work, amortised over the views)
+    // One group per step.  (The two-group step on packed operations of the single-view streamed pass was used here too
+    // until the end of round 2; a step of two groups leaves a test out only when neither needs it, and with the
+    // per-instance verdicts that costs more than the packed arithmetic saves: 8 views at 8192^2 3.77 -> 3.73 ms,
+    // without the occlusion test 3.11 -> 3.05 ms, without the classification 5.30 -> 5.21 ms.)
     Xform m[NG];
-    float4 wc[NG], wa[NG];  // scalar form
-    Centre2 wc2[NG / 2 + 1];
-    Axis2 wa2[NG / 2 + 1];
-    constexpr bool kPacked = NG % 2 == 0 && NT;
+    float4 wc[NG], wa[NG];
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const uint32_t slot = wave * NG + k;
         m[k].c0 = s_x[slot][0]; m[k].c1 = s_x[slot][1]; m[k].c2 = s_x[slot][2]; m[k].c3 = s_x[slot][3];
-    }
-    if constexpr (kPacked) {
-#pragma unroll
-        for (int k = 0; k < NG; k += 2) {
-            const uint32_t slot = wave * NG + k;
-            wc2[k / 2] = world_centre2(m[k], m[k + 1], s_scale[slot], s_scale[slot + 1], c[k], c[k + 1]);
-            wa2[k / 2] = world_axis2(m[k], m[k + 1], a[k], a[k + 1]);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NG; k++) {
-            wc[k] = world_centre(m[k], s_scale[wave * NG + k], c[k]);
-            wa[k] = world_axis(m[k], a[k]);
-        }
+        wc[k] = world_centre(m[k], s_scale[slot], c[k]);
+        wa[k] = world_axis(m[k], a[k]);
     }
     for (uint32_t i = 0; i < vs.n; i++) {
         const ViewConst &v = VP ? view_dev[i] : vs.v[i];
         uint64_t *__restrict__ mask = vs.mask[i];
         uint32_t count = 0;
-        if constexpr (kPacked) {
 #pragma unroll
-            for (int k = 0; k < NG; k += 2) {
-                const uint32_t slot = wave * NG + k;
-                bool vis0 = false, vis1 = false;
-                const uint32_t n0 = s_rec[slot].z, n1 = s_rec[slot + 1].z;
-                const uint32_t f0 = flags_of(slot, i), f1 = flags_of(slot + 1, i);
-                const bool gone0 = (f0 & kInstCulled) != 0u, gone1 = (f1 & kInstCulled) != 0u;
-                if (!(gone0 && gone1)) {
-                    // a test is left out only when neither group of the step needs it (a dropped group needs none)
-                    const uint32_t t2 = v.tests & (keep_of(gone0 ? 6u : f0) | keep_of(gone1 ? 6u : f1));
-                    tests2<NT, true>(t2, v, m[k], m[k + 1], wc2[k / 2], wa2[k / 2], a[k], a[k + 1], lane < n0 && !gone0, lane < n1 && !gone1,
-                                     vis0, vis1);
-                }
-                const uint64_t b0 = __ballot(vis0 && lane < n0), b1 = __ballot(vis1 && lane < n1);
-                if (lane == 0 && n0) mask[block_g0 + slot] = b0;
-                if (lane == 0 && n1) mask[block_g0 + slot + 1] = b1;
-                count += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NG; k++) {
-                const uint32_t slot = wave * NG + k;
-                const uint32_t n_valid = s_rec[slot].z;
-                const uint32_t f = flags_of(slot, i);
-                bool vis = false;
-                if (!(f & kInstCulled)) vis = pair_visible_prepared<NT>(v.tests & keep_of(f), v, m[k], wc[k], wa[k]) && (lane < n_valid);
-                const uint64_t ballot = __ballot(vis);
-                if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
-                count += (uint32_t)__popcll(ballot);
-            }
+        for (int k = 0; k < NG; k++) {
+            const uint32_t slot = wave * NG + k;
+            const uint32_t n_valid = s_rec[slot].z;
+            const uint32_t f = flags_of(slot, i);
+            bool vis = false;
+            if (!(f & kInstCulled)) vis = pair_visible_prepared<NT>(v.tests & keep_of(f), v, m[k], wc[k], wa[k]) && (lane < n_valid);
+            const uint64_t ballot = __ballot(vis);
+            if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
+            count += (uint32_t)__popcll(ballot);
         }
         if (lane == 0) s_count[i][wave] = count;
     }
