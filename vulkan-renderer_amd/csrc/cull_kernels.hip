@@ -1276,10 +1276,10 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     // what does not depend on the view is evaluated once per group: the transforms, the world-space
     // centre and radius, and the unit cone axis (for pairs no view tests with the cone that is wasted
     // work, amortised over the views)
-    // One group per step.  (The two-group step on packed operations of the single-view streamed pass was used here too
-    // until the end of round 2; a step of two groups leaves a test out only when neither needs it, and with the
-    // per-instance verdicts that costs more than the packed arithmetic saves: 8 views at 8192^2 3.77 -> 3.73 ms,
-    // without the occlusion test 3.11 -> 3.05 ms, without the classification 5.30 -> 5.21 ms.)
+    // One group per step.  (The two-group step on packed operations of the single-view streamed pass measured slower
+    // here: a step of two groups leaves a test out only when neither needs it, and with the per-instance verdicts
+    // that costs more than the packed arithmetic saves: 8 views at 8192^2 3.77 against 3.73 ms,
+    // without the occlusion test 3.11 against 3.05 ms, without the classification 5.30 against 5.21 ms.)
     Xform m[NG];
     float4 wc[NG], wa[NG];
 #pragma unroll
