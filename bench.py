@@ -351,7 +351,7 @@ def time_cpu(fn, budget_s, max_reps=400):
 def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False):
     """One measured leg of a cull workload.  scaling "weak": every rank culls a whole scene of its own
     (seed 42 + rank); "strong": ONE scene (seed 42) whose instances are split into `world` contiguous
-    shards, rank r generating and culling instances [r*I/N, (r+1)*I/N) - BASELINE config 4 as worded.
+    shards, rank r generating and culling instances [r*I/N, (r+1)*I/N) - configuration 4 as its statement words it (100 M pairs sharded over the GPUs).
     Returns a dict of measurements (same on every rank where it matters) plus the scene tensors."""
     args, mc, ctx, device = env.args, env.mc, env.ctx, env.device
     rank, world, multi, dist = env.rank, env.world, env.multi, env.dist
@@ -653,7 +653,7 @@ def run_cull(env, workload):
             out["cpu_baseline"] = cpu_baseline_cull(cone, sphere, xf, off, cnt, r["views"][-1], r["tests"], n_inst, per,
                                                     r["depth"], r["hiz_size"], workload)
     if world > 1 and args.scaling == "weak" and not args.no_strong_leg:
-        # the same job as BASELINE words config 4: ONE scene split over the ranks.  Reported beside the
+        # the same job as the statement of configuration 4 words it: ONE scene split over the ranks.  Reported beside the
         # weak-scaling value in the same line (the default `value` stays weak: fixed work per GPU).
         r.pop("scene")  # release the weak leg's scene before the second one is generated
         r2 = cull_leg(env, workload, "strong", steps=min(args.steps, 50), warmup=min(args.warmup, 5), gather_lists=args.gather_lists)
@@ -1084,7 +1084,7 @@ def main():
                     help="config4: projection without the reference's y flip, so that the Hi-Z test selects real mip levels")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="cull workloads with N ranks: weak = one whole scene per GPU (value = N scenes per step); strong = one "
-                         "scene split into N contiguous instance shards (BASELINE config 4 as worded)")
+                         "scene split into N contiguous instance shards (configuration 4 as its statement words it)")
     ap.add_argument("--no-strong-leg", action="store_true",
                     help="multi-rank weak runs also measure the strong-scaling form and report it as `strong_scaling`; this skips it")
     ap.add_argument("--hiz-size", type=int, nargs=2, default=(8192, 8192), metavar=("W", "H"))
