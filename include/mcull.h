@@ -406,7 +406,8 @@ int mcull_last_kernel_ms(mcull_ctx *ctx, float *ms);
  * `globals` supplies view/proj (gl_Position = proj*view*model*v, shader.mesh:73); the viewport is
  * (0,0,width,height), depth 0..1 (Engine.cpp:2413-2420).  clear != 0 (or a size change) clears the
  * image first; clear == 0 accumulates into the previous image.  Needs mcull_upload_meshlets and
- * mcull_upload_geometry (not SoA-only scenes).  The image feeds mcull_hiz_build(..., MCULL_MEM_DEVICE):
+ * mcull_upload_geometry (not SoA-only scenes), and the transforms the cull ran on: MCULL_E_STATE when a
+ * different number of them has been uploaded since.  The image feeds mcull_hiz_build(..., MCULL_MEM_DEVICE):
  * cull -> rasterise -> pyramid -> cull with MCULL_TEST_HIZ is the reference's two-phase frame
  * (Engine.cpp:2381-2551) without the raster hardware.  Stream-ordered. */
 int mcull_depth_rasterize(mcull_ctx *ctx, const mcull_globals *globals, uint32_t width, uint32_t height, int clear);

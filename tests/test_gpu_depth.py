@@ -392,3 +392,22 @@ def test_huge_triangles_go_through_the_job_queue(mc, O, monkeypatch, queue):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=110)
     assert out.returncode == 0 and "huge ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_transforms_replaced_since_the_cull_are_reported(mc, H, kitten):
+    """The list's drawIDs index the transforms: a rasteriser call after an upload of a different number of them is
+    refused (MCULL_E_STATE) instead of reading past the new array."""
+    ml = kitten["meshlets"]
+    g = H.create_globals(width=64, height=64, meshlet_count=len(ml))
+    with mc.Context(0) as c:
+        c.upload_meshlets(ml)
+        c.upload_geometry(kitten["vertices"], kitten["meshlet_data"])
+        c.upload_transforms(mc.reference_transforms(8))
+        c.cull(g, tests=3)
+        c.depth_rasterize(g, 64, 64)
+        c.upload_transforms(mc.reference_transforms(4))
+        with pytest.raises(mc.McullError) as e:
+            c.depth_rasterize(g, 64, 64)
+        assert e.value.status == mc.E_STATE
+        c.cull(g, tests=3)
+        c.depth_rasterize(g, 64, 64)

@@ -1431,6 +1431,10 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     // the list's meshlet ids index the AoS records: they must be the array the cull ran on
     if (o.last.scene.cone_axis_w != (const float4 *)c->cone.p)
         return fail(c, MCULL_E_STATE, "the last cull ran on adopted SoA bounds, not on the uploaded meshlets");
+    // ... and the list's drawIDs index the transforms (and the per-instance matrices derived from them here)
+    if ((uint64_t)o.last.scene.n_instances != c->n_instances)
+        return fail(c, MCULL_E_STATE, "the transforms were replaced by %llu since the last cull ran on %u",
+                    (unsigned long long)c->n_instances, o.last.scene.n_instances);
     const size_t bytes = (size_t)width * height * 4;
     const bool resized = c->depth_w != width || c->depth_h != height;
     if (int rc = ensure(c, c->depth, bytes)) return rc;
