@@ -19,6 +19,7 @@
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
 //                workgroup step), list order unspecified.
 #include <cstring>
+#include <type_traits>
 
 #include "mcull_internal.h"
 
@@ -708,27 +709,43 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
     // Both tables are read with a fixed number of independent loads (coordinates past the rectangle repeat its last
     // row / column), so that a thread waits for memory once per table, not once per texel.
     if (want_open && v.strips) {
-        // up to 4 x 8 cells of the strips (64 x 8 pixels each), or of the 64 x 64 blocks stored behind them when the
-        // rectangle is taller than that and lies inside what the blocks cover
-        const int32_t cx0 = x_lo >> 6, ncx = (x_hi >> 6) - cx0 + 1;
+        // up to 4 x 8 cells of the strips (64 x 8 pixels each), or - when the rectangle is larger than that and lies
+        // inside what they cover - of the tables behind them: cells of 64, 128, 256 and 512 pixels square
+        const uint32_t sw = v.strips_w, sh = (v.h0 + 7u) >> 3;
+        int32_t cx0 = x_lo >> 6, ncx = (x_hi >> 6) - cx0 + 1;
         int32_t cy0 = y_lo >> 3, ncy = (y_hi >> 3) - cy0 + 1;
         const float *table = v.strips;
-        if (ncy > 8) {
+        uint32_t row_len = sw;
+        if (ncx > 4 || ncy > 8) {
             const uint32_t cover_w = ((v.w0 >> 3) + 63u) / 64u * 512u, cover_h = ((v.h0 >> 3) + 63u) / 64u * 512u;
-            cy0 = y_lo >> 6;
-            ncy = ((uint32_t)x_hi < cover_w && (uint32_t)y_hi < cover_h) ? (y_hi >> 6) - cy0 + 1 : 99;
-            table = v.strips + (size_t)v.strips_w * ((v.h0 + 7u) >> 3);
+            ncx = ncy = 99;
+            if ((uint32_t)x_hi < cover_w && (uint32_t)y_hi < cover_h) {
+                size_t off = (size_t)sw * sh;
+                uint32_t cw = sw, ch = (v.h0 + 63u) >> 6;
+#pragma unroll
+                for (uint32_t j = 0; j <= 3; j++) {
+                    const int32_t nx = (x_hi >> (6 + j)) - (x_lo >> (6 + j)) + 1, ny = (y_hi >> (6 + j)) - (y_lo >> (6 + j)) + 1;
+                    if (ncx > 4 && nx <= 4 && ny <= 8) {  // the finest table that will do
+                        cx0 = x_lo >> (6 + j); cy0 = y_lo >> (6 + j); ncx = nx; ncy = ny;
+                        table = v.strips + off;
+                        row_len = cw;
+                    }
+                    off += (size_t)cw * ch;
+                    cw = (cw + 1u) >> 1;
+                    ch = (ch + 1u) >> 1;
+                }
+            }
         }
         if (ncx <= 4 && ncy <= 8) {
             const float ql = lower(c[2] - e[2]);
             const float nz_lb = (ql - fabsf(ql) * slack) - 1.0e-30f;
             float smax = -__builtin_inff();
-            const float *row0 = table + (size_t)cy0 * v.strips_w + cx0;
+            const float *row0 = table + (size_t)cy0 * row_len + cx0;
             // one row of cells per iteration, its (at most four) loads independent of each other: scattered 4-byte
             // loads are what this kernel waits for, so none is issued for rows the rectangle does not have
             const int32_t c1 = min(1, ncx - 1), c2 = min(2, ncx - 1), c3 = ncx - 1;
             for (int32_t j = 0; j < ncy; j++) {
-                const float *row = row0 + (size_t)j * v.strips_w;
+                const float *row = row0 + (size_t)j * row_len;
                 smax = fmaxf(fmaxf(smax, fmaxf(row[0], row[c1])), fmaxf(row[c2], row[c3]));
             }
             if (nz_lb >= smax - 0.05f) return kInstOpen;  // it cannot be hidden as well
@@ -1176,20 +1193,65 @@ __global__ __launch_bounds__(kBlock) void cull_mask_kernel(
 // ------------------------------------------------------------------------------------------------
 // The same pass for several views at once: the bounds, records and transforms are read once and every
 // view's tests run on them (the 32 bytes per pair are the dominant traffic of a streamed scene, so
-// eight views cost one read instead of eight).  Each view has its own mask and tile counters; the
-// per-view constants stay in the kernel-argument segment and are fetched by scalar loads inside the
-// (wave-uniform) view loop.
+// eight views cost one read instead of eight).  Each view has its own mask and tile counters.
+// The views are taken two at a time (ViewHot2: element e of every pair of constants belongs to view 2p + e), so
+// that the frustum and cone tests of both run on packed binary32 instructions - two independent IEEE operations
+// per instruction, and unlike two GROUPS per step (tests2) a step of two VIEWS gives up nothing: which tests a
+// view still needs is known per group and view, and an instruction that serves one view costs what it costs for
+// two.  A pair's constants are fetched once per wave, in one batch of scalar loads in front of the groups that
+// use them (see pin_sgpr), not per group and per use.
+// One byte per instance and view slot, written by the instance level for the mask pass: bit 3 = the instance is still
+// in the running for the view (clear: every meshlet is rejected, or the slot is unused), bits 0-2 = the MCULL_TEST_*
+// its meshlets still need there.  f = the instance level's verdict (kInst*), tests = the view's tests.
+__host__ __device__ inline uint32_t view_need_byte(uint32_t f, uint32_t tests) {
+    if (f & kInstCulled) return 0u;
+    return 8u | (tests & 7u & ~(((f & kInstInside) ? (uint32_t)MCULL_TEST_FRUSTUM : 0u) | ((f & kInstOpen) ? (uint32_t)MCULL_TEST_HIZ : 0u)));
+}
+
 struct ViewSet {
     ViewConst v[MCULL_MAX_VIEWS];
+    ViewHot2 hot[MCULL_MAX_VIEWS / 2];
     uint64_t *mask[MCULL_MAX_VIEWS];
     uint32_t *tile_counts[MCULL_MAX_VIEWS];
     uint32_t n;
 };
 
+void fill_view_pairs(uint32_t n_views, const ViewConst *const *views, ViewHot2 *hot) {
+    std::memset(hot, 0, sizeof(ViewHot2) * (MCULL_MAX_VIEWS / 2));
+    for (uint32_t i = 0; i < n_views; i++) {
+        ViewHot2 &h = hot[i >> 1];
+        const uint32_t e = i & 1u;
+        for (int p = 0; p < 5; p++)
+            for (int j = 0; j < 4; j++) h.frustum[p][j][e] = views[i]->frustum[p][j];
+        for (int j = 0; j < 3; j++) h.cam[j][e] = views[i]->cam[j];
+        h.tests[e] = views[i]->tests;
+        h.force_exact[e] = views[i]->force_exact;
+    }
+}
+
+// The same from device-resident view constants (the *_device_globals calls): one thread per view slot.
+__global__ void pack_view_pairs_kernel(const ViewConst *__restrict__ view_dev, uint32_t n_views, ViewHot2 *__restrict__ hot) {
+    const uint32_t i = threadIdx.x;
+    if (i >= MCULL_MAX_VIEWS) return;
+    ViewHot2 &h = hot[i >> 1];
+    const uint32_t e = i & 1u;
+    const bool real = i < n_views;
+    for (int p = 0; p < 5; p++)
+        for (int j = 0; j < 4; j++) h.frustum[p][j][e] = real ? view_dev[i].frustum[p][j] : 0.0f;
+    for (int j = 0; j < 3; j++) h.cam[j][e] = real ? view_dev[i].cam[j] : 0.0f;
+    h.tests[e] = real ? view_dev[i].tests : 0u;
+    h.force_exact[e] = real ? view_dev[i].force_exact : 0u;
+}
+
+hipError_t launch_pack_view_pairs(const ViewConst *view_dev, uint32_t n_views, ViewHot2 *hot, hipStream_t st) {
+    hipLaunchKernelGGL(pack_view_pairs_kernel, dim3(1), dim3(64), 0, st, view_dev, n_views, hot);
+    return hipGetLastError();
+}
+
 // The instance level of the multi-view pass: one thread per instance, which works out what does not depend on the view
 // once and then instance_classify's verdict for every view (the view's constants are wave-uniform: scalar loads).
-// flags[instance][slot] = the verdict for that view (zero for unused slots), eight bytes stored at once; the mask pass
-// stages them with the instance's group record and drops or narrows the tests per view.  (One thread per instance AND
+// flags[instance][slot] = what the mask pass still has to do for the instance in that view (view_need_byte; zero for
+// unused slots), eight bytes stored at once; the mask pass stages them with the instance's group record.  (One thread per instance AND
 // view read the view constants per lane and repeated the instance's part eight times: 293 us for 781 250 instances
 // and 8 views.  A byte that only says "outside the frustum" did not pay in front of a pass that waited for its texel
 // reads: 5.35 against 5.14 ms for 8 views at 8192^2.  With the occlusion verdicts and the tests it lets the pass leave
@@ -1207,8 +1269,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             const ViewConst &v = view_dev ? view_dev[slot] : vs.v[slot];
             const uint32_t f = classify_geometry(q, v, true, v.tests);
             found += f != 0u;
-            if (slot < 4u) lo |= f << (8u * slot);
-            else hi |= f << (8u * (slot - 4u));
+            const uint32_t need = view_need_byte(f, v.tests);
+            if (slot < 4u) lo |= need << (8u * slot);
+            else hi |= need << (8u * (slot - 4u));
         }
         flags[i] = make_uint2(lo, hi);
     }
@@ -1222,38 +1285,231 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     }
 }
 
-// VP: view i's constants are read from view_dev[i] (device memory, written by an earlier kernel of the stream)
-// instead of the argument segment; masks, counters and the uniform meshlet count still come from `vs`.
+// A wave-uniform value is wanted in scalar registers HERE: the empty statement makes the compiler finish the
+// scalar loads that produce it at this point - as one batch with one wait, when several values are pinned in a
+// row - instead of sinking each load into the conditional block that first uses it, where every wave that gets
+// there waits for it on its own.
+template <typename T>
+__device__ __forceinline__ void pin_sgpr(T &x) {
+    asm volatile("" : "+s"(x));
+}
+
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+// frustumCull and coneCull (shader.task:37-56) of one pair against two views; on entry k0 / k1 say that the pair is
+// out of the running for view 0 / 1 already (its lane holds no meshlet, or the instance level has dropped the
+// instance for that view), t0 / t1 are the tests each view still needs (wave-uniform).  w = world-space centre and
+// radius, wa = unit world-space axis and coneW (world_centre, world_axis: IEEE, once for all views).
+// The frustum test is the IEEE expression itself on packed operations.  The cone test is guarded-exact like
+// cone_culled: its fast form is  dot(axis, v) * rsq(dot(v, v))  with fused multiply-adds, which lies within 2.5e-6
+// of the IEEE expression's value when both are ordinary numbers (each within about 1e-6 of the real quotient: a dozen
+// roundings of terms of magnitude <= 1 on one side, five and two units of the reciprocal square root on the other), so a
+// margin beyond 1e-5 decides; the other lanes evaluate the IEEE expression.
+// Lane masks instead of per-lane booleans: which pairs are still in the running is kept as one 64-bit scalar per
+// view, comparisons produce ballots, and the little logic between them runs on the scalar unit.
+__device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// v[lane L] = s, for a compile-time L: one instruction, no comparison and no change of the execution mask
+template <int L>
+__device__ __forceinline__ void set_lane(uint32_t &v, uint32_t s) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
+}
+
+// What the cone test needs of one pair, whatever the view: the world-space axis normalised with v_rsq_f32 (its error
+// is part of the fast form's bound), coneW, and -coneW^2 - a NaN when the fast form does not apply to the pair (coneW
+// negative, huge or a NaN, or an axis that cannot be normalised), which makes every fast comparison below fail.
+// The IEEE axis is evaluated where a lane needs it.
+struct ConePair {
+    float ax, ay, az, cw, ncw2;
+};
+
+__device__ __forceinline__ ConePair cone_pair(const Xform &m, float4 a) {
+    const float nx = __builtin_fmaf(m.c2.x, a.z, __builtin_fmaf(m.c1.x, a.y, m.c0.x * a.x));
+    const float ny = __builtin_fmaf(m.c2.y, a.z, __builtin_fmaf(m.c1.y, a.y, m.c0.y * a.x));
+    const float nz = __builtin_fmaf(m.c2.z, a.z, __builtin_fmaf(m.c1.z, a.y, m.c0.z * a.x));
+    const float la = __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx));
+    const float ia = __builtin_amdgcn_rsqf(la);
+    ConePair c;
+    c.ax = nx * ia; c.ay = ny * ia; c.az = nz * ia;
+    c.cw = a.w;
+    c.ncw2 = (ordinary(la) && a.w >= 0.0f && a.w < 1.0e9f) ? -(a.w * a.w) : __builtin_nanf("");
+    return c;
+}
+
+// normalize(mat3(model) * cone.xyz) (shader.task:95) from memory, for the rare lanes that need the IEEE value after
+// the registers that held the matrix and the axis have gone to other uses
+__device__ __noinline__ float4 world_axis_again(const float4 *__restrict__ t, const float4 *__restrict__ axis) {
+    Xform m;
+    m.c0 = t[0]; m.c1 = t[1]; m.c2 = t[2]; m.c3 = t[3];
+    return world_axis(m, *axis);
+}
+
+// coneCull as written (shader.task:37-41), from the unit world-space axis wa = {axis, coneW}, the world-space centre w and
+// the camera position: the IEEE expression.  Not inlined: it is the rare path of the cone test below.
+__device__ __noinline__ bool cone_exact(float4 wa, float4 w, float camx, float camy, float camz) {
+    const float vx = camx - w.x, vy = camy - w.y, vz = camz - w.z;
+    const float ie = 1.0f / sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+    return dot3(wa.x, wa.y, wa.z, vx * ie, vy * ie, vz * ie) < -wa.w;
+}
+
+// frustumCull (shader.task:43-56) of one pair against two views: the IEEE expression itself on packed operations.
+// Returns the lanes culled by view 0 / view 1.  The forty plane coefficients come in through scalar loads here, where
+// a group needs them (the instance level usually has settled the frustum test for the whole instance).
+__device__ __forceinline__ void frustum2(const ViewHot2 *__restrict__ hot, float4 w, uint64_t &c0, uint64_t &c1) {
+    const f2v wx = splat(w.x), wy = splat(w.y), wz = splat(w.z), r = splat(w.w);
+    f2v dmin = splat(__builtin_inff());
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const f2v nx = {hot->frustum[i][0][0], hot->frustum[i][0][1]}, ny = {hot->frustum[i][1][0], hot->frustum[i][1][1]};
+        const f2v nz = {hot->frustum[i][2][0], hot->frustum[i][2][1]}, nw = {hot->frustum[i][3][0], hot->frustum[i][3][1]};
+        const f2v d = (dot3v(nx, ny, nz, wx, wy, wz) + nw) + r;
+        // "some d < 0" as "the smallest d < 0": fminf skips a NaN, and a NaN d culls nothing either
+        dmin.x = fminf(dmin.x, d.x);
+        dmin.y = fminf(dmin.y, d.y);
+    }
+    c0 = __ballot(dmin.x < 0.0f);
+    c1 = __ballot(dmin.y < 0.0f);
+}
+
+// coneCull (shader.task:37-41) of one pair against two views, guarded-exact:
+//   culled  <=>  d < -coneW,  d = dot(axis, v) / |v|,  v = camera - centre.
+// Fast form, without a square root: with p = dot(axis, v), L = dot(v, v) and coneW >= 0,
+//   d < -coneW  <=>  p < 0 and p^2 > coneW^2 L,          u = p^2 - coneW^2 L = L (d - coneW)(d + coneW),
+// and since |d - coneW| <= 2,  |u| > 2.4e-5 L  implies  |d + coneW| > 1.2e-5.  The fast p, L and u (fused
+// multiply-adds, the axis normalised with v_rsq_f32) lie within 1e-6 L of their real values and the IEEE
+// expression's d within 2.5e-6 of its real value, so beyond that margin both decide alike.  Lanes inside it, and lanes
+// whose numbers are not ordinary - L outside [1e-30, 1e30] (its bit pattern is range-checked as an integer), a NaN
+// anywhere, a pair whose -coneW^2 is the NaN of cone_pair - fail a comparison and are returned in slow0 / slow1 for the
+// IEEE expression.  c0 / c1: the lanes the fast form culls.
+__device__ __forceinline__ void cone2_fast(f2v camx, f2v camy, f2v camz, float4 w, const ConePair &cp, uint64_t &c0, uint64_t &c1,
+                                           uint64_t &sure0, uint64_t &sure1) {
+    const f2v vx = camx - splat(w.x), vy = camy - splat(w.y), vz = camz - splat(w.z);
+    const f2v lv = fma2(vz, vz, fma2(vy, vy, vx * vx));
+    const f2v p = fma2(splat(cp.az), vz, fma2(splat(cp.ay), vy, splat(cp.ax) * vx));
+    const f2v u = fma2(splat(cp.ncw2), lv, p * p);
+    const f2v thr = lv * splat(2.4e-5f);
+    // min(-p, u) > 0  <=>  p < 0 and u > 0 (a NaN compares false)
+    c0 = __ballot(fminf(-p.x, u.x) > 0.0f);
+    c1 = __ballot(fminf(-p.y, u.y) > 0.0f);
+    constexpr uint32_t kLo = 0x0DA24260u, kSpan = 0x7149F2CAu - 0x0DA24260u;  // bit patterns of 1e-30f and 1e30f
+    const bool r0 = __float_as_uint(lv.x) - kLo < kSpan, r1 = __float_as_uint(lv.y) - kLo < kSpan;
+    sure0 = __ballot(fabsf(u.x) > (r0 ? thr.x : __builtin_inff()));
+    sure1 = __ballot(fabsf(u.y) > (r1 ? thr.y : __builtin_inff()));
+}
+
+// occlusionCull of one pair against one view (the clip-space centre is the IEEE expression, as in cone_and_occlusion)
+__device__ __forceinline__ bool occlusion1(const ViewConst &v, float4 w, bool live) {
+    const float cx = ((v.vp[0] * w.x + v.vp[4] * w.y) + v.vp[8] * w.z) + v.vp[12];
+    const float cy = ((v.vp[1] * w.x + v.vp[5] * w.y) + v.vp[9] * w.z) + v.vp[13];
+    const float cz = ((v.vp[2] * w.x + v.vp[6] * w.y) + v.vp[10] * w.z) + v.vp[14];
+    const float cw = ((v.vp[3] * w.x + v.vp[7] * w.y) + v.vp[11] * w.z) + v.vp[15];
+    return occluded(v, cx, cy, cz, cw, v.proj11 * w.w, live);
+}
+
+// The multi-view mask pass.  It is bound by instruction issue, vector and scalar alike (a SIMD issues one of each per
+// turn, from different waves: measured, per-wave time = 8 waves x the larger of the two counts), so it is written to
+// spend few of either:
+//  * lane masks in scalar registers instead of per-lane booleans, comparisons as ballots;
+//  * the instance level's verdicts arrive as ready-made "tests still needed" bytes (view_need_byte);
+//  * the views are taken two at a time on packed operations (ViewHot2), the four pairs unrolled so that every shift,
+//    lane index and constant address is an immediate;
+//  * the cone test's fast form needs no square root and five comparisons per view (cone2_fast);
+//  * the ballots of a wave - one per group and view - are gathered in the lanes of two registers (lane = view * NG +
+//    group, v_writelane), go to LDS with one instruction per wave, and leave the workgroup with ONE store
+//    instruction, each view's words contiguous; their popcounts are taken from those lanes at the end.
+// The occlusion test runs last, after the frustum and cone tests of all views, on the gathered ballots: its texel read
+// is the one data-dependent memory access, and the fewer pairs reach it the better.
+// VP: the views' constants are read from view_dev[i] / hot_dev[i / 2] (device memory, written by earlier kernels of the
+// stream) instead of the argument segment; masks, counters and the uniform meshlet count still come from `vs`.
+#ifndef MCULL_VIEWS_NG
+#define MCULL_VIEWS_NG 2
+#endif
+constexpr int kViewsNG = MCULL_VIEWS_NG;  // groups per wave of the multi-view pass
+
+// What a wave holds of one of its groups while the views go by.
+struct ViewsGroup {
+    float4 wc;        // world-space centre and radius (world_centre: IEEE)
+    ConePair cp;
+    uint64_t in;      // lanes that hold a meshlet
+    uint32_t nb_lo, nb_hi;  // the instance's need bytes for view slots 0-3 / 4-7
+};
+
+// Frustum and cone tests of group K of the wave against the views 2P and 2P + 1; the survivors' ballots go to lanes
+// (2P) * NG + K and (2P + 1) * NG + K of blo / bhi.
+template <int P, int K, int NG, typename AxisFn>
+__device__ __forceinline__ void views_pair_step(const ViewsGroup &g, const ViewHot2 *__restrict__ hot, const f2v *__restrict__ cam,
+                                                uint32_t exact_all, const ViewConst *__restrict__ views, AxisFn &&exact_axis,
+                                                uint32_t &blo, uint32_t &bhi) {
+    const uint32_t nb = (P < 2 ? g.nb_lo : g.nb_hi) >> (16 * (P & 1));  // bytes 2P and 2P + 1 of the instance's eight
+    uint64_t live0 = (nb & 8u) ? g.in : 0ull, live1 = (nb & 0x800u) ? g.in : 0ull;
+    if ((nb & 0x0101u) && (live0 | live1)) {
+        uint64_t c0, c1;
+        frustum2(hot, g.wc, c0, c1);
+        if (nb & 0x0001u) live0 &= ~c0;
+        if (nb & 0x0100u) live1 &= ~c1;
+    }
+    if ((nb & 0x0202u) && (live0 | live1)) {
+        const f2v camx = cam[0], camy = cam[1], camz = cam[2];
+        uint64_t c0, c1, sure0, sure1;
+        cone2_fast(camx, camy, camz, g.wc, g.cp, c0, c1, sure0, sure1);
+        if (exact_all & (1u << (2 * P))) sure0 = 0;
+        if (exact_all & (2u << (2 * P))) sure1 = 0;
+        const uint64_t slow0 = (nb & 0x0002u) ? live0 & ~sure0 : 0ull, slow1 = (nb & 0x0200u) ? live1 & ~sure1 : 0ull;
+        if (slow0 | slow1) {  // rare: the IEEE expression, in functions of their own so that their registers are not the kernel's
+            const float4 wa = exact_axis();
+            if (slow0) c0 = (c0 & ~slow0) | (__ballot(cone_exact(wa, g.wc, camx.x, camy.x, camz.x)) & slow0);
+            if (slow1) c1 = (c1 & ~slow1) | (__ballot(cone_exact(wa, g.wc, camx.y, camy.y, camz.y)) & slow1);
+            if (slow0) note_slow(views[2 * P], lane_of(slow0));
+            if (slow1) note_slow(views[2 * P + 1], lane_of(slow1));
+        }
+        if (nb & 0x0002u) live0 &= ~c0;
+        if (nb & 0x0200u) live1 &= ~c1;
+    }
+    set_lane<(2 * P) * NG + K>(blo, (uint32_t)live0);
+    set_lane<(2 * P) * NG + K>(bhi, (uint32_t)(live0 >> 32));
+    set_lane<(2 * P + 1) * NG + K>(blo, (uint32_t)live1);
+    set_lane<(2 * P + 1) * NG + K>(bhi, (uint32_t)(live1 >> 32));
+}
+
 template <int NG, bool NT, bool VP = false>
 __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     const float4 *__restrict__ cone_axis_w, const float4 *__restrict__ centre_radius,
     const float4 *__restrict__ transforms, const float *__restrict__ xf_scale,
     const uint4 *__restrict__ group_rec, uint32_t groups_per_instance, uint32_t n_groups, ViewSet vs,
-    const ViewConst *__restrict__ view_dev, const uint2 *__restrict__ view_flags, const uint32_t *__restrict__ useful,
-    uint32_t *__restrict__ useful_report) {
+    const ViewConst *__restrict__ view_dev, const ViewHot2 *__restrict__ hot_dev, const uint2 *__restrict__ view_flags,
+    const uint32_t *__restrict__ useful, uint32_t *__restrict__ useful_report) {
+    static_assert(NG == 1 || NG == 2 || NG == 4, "the lanes of a view's groups are summed with lane shuffles");
     constexpr uint32_t kGroups = kWaves * NG;
     __shared__ uint4 s_rec[kGroups];
     __shared__ float4 s_x[kGroups][4];
     __shared__ float s_scale[kGroups];
     __shared__ uint32_t s_count[MCULL_MAX_VIEWS][kWaves];
-    __shared__ uint2 s_vf[kGroups];  // the instance's byte per view slot (classify_views_kernel), or zero
+    __shared__ uint2 s_vf[kGroups];  // the instance's need byte per view slot (classify_views_kernel)
+    __shared__ uint64_t s_ballot[MCULL_MAX_VIEWS][kGroups];
+    // the camera position of every view, two views to an element: staged by threads that have no group record to
+    // fetch, read back as broadcasts
+    __shared__ f2v s_cam[MCULL_MAX_VIEWS / 2][4];
     // how much the pre-pass found, left where the host can look at it later without waiting (host-mapped memory)
     if (useful_report && blockIdx.x == 0 && threadIdx.x == 0) *useful_report = *useful;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t block_g0 = blockIdx.x * kGroups;
     if (threadIdx.x < kGroups) {
         const uint32_t g = block_g0 + threadIdx.x;
         GroupInfo gi = group_lookup(g < n_groups ? g : n_groups - 1u, group_rec, groups_per_instance, vs.v[0].uniform_count);
         if (g >= n_groups) gi.count = 0;
         s_rec[threadIdx.x] = make_uint4(gi.inst, gi.first_meshlet, gi.count, gi.local_group);
-        s_vf[threadIdx.x] = view_flags ? view_flags[gi.inst] : make_uint2(0u, 0u);
+    } else if (threadIdx.x >= 64u && threadIdx.x < 64u + (MCULL_MAX_VIEWS / 2) * 3u) {
+        const uint32_t p = (threadIdx.x - 64u) / 3u, j = (threadIdx.x - 64u) % 3u;
+        const ViewHot2 *hot = VP ? hot_dev + p : vs.hot + p;
+        s_cam[p][j] = f2v{hot->cam[j][0], hot->cam[j][1]};
     }
     __syncthreads();
     if (threadIdx.x < kGroups * 4) {
         const uint32_t k = threadIdx.x >> 2, j = threadIdx.x & 3u;
         s_x[k][j] = transforms[(size_t)s_rec[k].x * 4 + j];
         if (j == 0) s_scale[k] = xf_scale[s_rec[k].x];
+        if (j == 1 && view_flags) s_vf[k] = view_flags[s_rec[k].x];  // beside the bounds, not in front of them
     }
     float4 a[NG], c[NG];
 #pragma unroll
@@ -1264,49 +1520,98 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         a[k] = load_bounds<NT>(cone_axis_w + id);
         c[k] = load_bounds<NT>(centre_radius + id);
     }
+    // without an instance level every view slot in use needs all of its tests; which views want every pair through
+    // the IEEE expressions (two bits per pair of views)
+    uint32_t def_lo = 0, def_hi = 0, exact_all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < MCULL_MAX_VIEWS / 2; q++) {
+        const ViewHot2 *hot = VP ? hot_dev + q : vs.hot + q;
+        const uint32_t two = (2u * q < vs.n ? (8u | (hot->tests[0] & 7u)) : 0u) | ((2u * q + 1u < vs.n ? (8u | (hot->tests[1] & 7u)) : 0u) << 8);
+        if (q < 2u) def_lo |= two << (16u * q);
+        else def_hi |= two << (16u * (q - 2u));
+        exact_all |= ((hot->force_exact[0] ? 1u : 0u) | (hot->force_exact[1] ? 2u : 0u)) << (2u * q);
+    }
+    def_lo = __builtin_amdgcn_readfirstlane(def_lo);  // (uniform already; loads from hot_dev come back in vector registers)
+    def_hi = __builtin_amdgcn_readfirstlane(def_hi);
+    exact_all = __builtin_amdgcn_readfirstlane(exact_all);
     __syncthreads();
-    // the byte of view i for the group in `slot`: wave-uniform
-    auto flags_of = [&](uint32_t slot, uint32_t i) {
-        const uint2 f = s_vf[slot];
-        return __builtin_amdgcn_readfirstlane(((i < 4u ? f.x : f.y) >> (8u * (i & 3u))) & 0xffu);
+    // what does not depend on the view, once per group
+    ViewsGroup grp[NG];
+    uint32_t any_hiz = 0;
+    auto xform_of = [&](uint32_t slot) {
+        Xform m;
+        m.c0 = s_x[slot][0]; m.c1 = s_x[slot][1]; m.c2 = s_x[slot][2]; m.c3 = s_x[slot][3];
+        return m;
     };
-    auto keep_of = [](uint32_t f) {  // the tests a group with these flags still needs
-        return ~(((f & kInstInside) ? (uint32_t)MCULL_TEST_FRUSTUM : 0u) | ((f & kInstOpen) ? (uint32_t)MCULL_TEST_HIZ : 0u));
-    };
-    // what does not depend on the view is evaluated once per group: the transforms, the world-space
-    // centre and radius, and the unit cone axis (for pairs no view tests with the cone that is wasted
-    // work, amortised over the views)
-    // One group per step.  (The two-group step on packed operations of the single-view streamed pass measured slower
-    // here: a step of two groups leaves a test out only when neither needs it, and with the per-instance verdicts
-    // that costs more than the packed arithmetic saves: 8 views at 8192^2 3.77 against 3.73 ms,
-    // without the occlusion test 3.11 against 3.05 ms, without the classification 5.30 against 5.21 ms.)
-    Xform m[NG];
-    float4 wc[NG], wa[NG];
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const uint32_t slot = wave * NG + k;
-        m[k].c0 = s_x[slot][0]; m[k].c1 = s_x[slot][1]; m[k].c2 = s_x[slot][2]; m[k].c3 = s_x[slot][3];
-        wc[k] = world_centre(m[k], s_scale[slot], c[k]);
-        wa[k] = world_axis(m[k], a[k]);
-    }
-    for (uint32_t i = 0; i < vs.n; i++) {
-        const ViewConst &v = VP ? view_dev[i] : vs.v[i];
-        uint64_t *__restrict__ mask = vs.mask[i];
-        uint32_t count = 0;
-#pragma unroll
-        for (int k = 0; k < NG; k++) {
-            const uint32_t slot = wave * NG + k;
-            const uint32_t n_valid = s_rec[slot].z;
-            const uint32_t f = flags_of(slot, i);
-            bool vis = false;
-            if (!(f & kInstCulled)) vis = pair_visible_prepared<NT>(v.tests & keep_of(f), v, m[k], wc[k], wa[k]) && (lane < n_valid);
-            const uint64_t ballot = __ballot(vis);
-            if (lane == 0 && n_valid) mask[block_g0 + slot] = ballot;
-            count += (uint32_t)__popcll(ballot);
+        const Xform m = xform_of(slot);
+        grp[k].wc = world_centre(m, s_scale[slot], c[k]);
+        grp[k].cp = cone_pair(m, a[k]);
+        const uint32_t n_valid = __builtin_amdgcn_readfirstlane(s_rec[slot].z);
+        grp[k].in = n_valid >= 64u ? ~0ull : (1ull << n_valid) - 1ull;
+        if (view_flags) {
+            const uint2 f = s_vf[slot];
+            grp[k].nb_lo = __builtin_amdgcn_readfirstlane(f.x);
+            grp[k].nb_hi = __builtin_amdgcn_readfirstlane(f.y);
+        } else {
+            grp[k].nb_lo = def_lo;
+            grp[k].nb_hi = def_hi;
         }
-        if (lane == 0) s_count[i][wave] = count;
+        any_hiz |= (grp[k].nb_lo | grp[k].nb_hi) & 0x04040404u;
     }
+    const ViewConst *views = VP ? view_dev : vs.v;
+    const ViewHot2 *hots = VP ? hot_dev : vs.hot;
+    uint32_t blo = 0, bhi = 0;
+    auto do_pair = [&](auto P) {
+        constexpr int Pc = decltype(P)::value;
+        if (2u * Pc >= vs.n) return;
+        auto step = [&](auto K) {
+            constexpr int Kc = decltype(K)::value;
+            if constexpr (Kc < NG) {
+                const uint32_t slot = wave * NG + Kc;
+                // the IEEE axis of the lane's pair, for the lanes that leave the fast cone test: its bounds are read again
+                auto exact_axis = [&]() {
+                    const uint4 r = s_rec[slot];
+                    const uint32_t last = r.z ? r.z - 1u : 0u;
+                    return world_axis_again(transforms + (size_t)r.x * 4, cone_axis_w + r.y + (lane < last ? lane : last));
+                };
+                views_pair_step<Pc, Kc, NG>(grp[Kc], hots + Pc, s_cam[Pc], exact_all, views, exact_axis, blo, bhi);
+            }
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    };
+    do_pair(std::integral_constant<int, 0>{}); do_pair(std::integral_constant<int, 1>{});
+    do_pair(std::integral_constant<int, 2>{}); do_pair(std::integral_constant<int, 3>{});
+    // ---- the occlusion test of the (view, group) combinations that still want it, on the ballots gathered so far
+    if (any_hiz) {
+        for (uint32_t i = 0; i < vs.n; i++) {
+            const ViewConst &v = views[i];
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                const uint32_t nb = ((i < 4u ? grp[k].nb_lo : grp[k].nb_hi) >> (8u * (i & 3u)));
+                if (!(nb & MCULL_TEST_HIZ)) continue;
+                const uint32_t l = i * NG + k;
+                const uint64_t live = ((uint64_t)lane_u32(bhi, l) << 32) | lane_u32(blo, l);
+                if (!live) continue;
+                const uint64_t left = live & ~__ballot(occlusion1(v, grp[k].wc, lane_of(live)));
+                if (lane == l) { blo = (uint32_t)left; bhi = (uint32_t)(left >> 32); }
+            }
+        }
+    }
+    // ---- ballots and counts: lane view * NG + group owns one of each
+    if (lane < vs.n * NG) s_ballot[lane / NG][wave * NG + lane % NG] = ((uint64_t)bhi << 32) | blo;
+    uint32_t pop = __popc(blo) + __popc(bhi);
+    if (NG >= 2) pop += __shfl_xor(pop, 1, 64);
+    if (NG >= 4) pop += __shfl_xor(pop, 2, 64);
+    if (lane < vs.n * NG && lane % NG == 0u) s_count[lane / NG][wave] = pop;
     __syncthreads();
+    for (uint32_t t = threadIdx.x; t < vs.n * kGroups; t += kBlock) {
+        const uint32_t i = t / kGroups, slot = t % kGroups;
+        if (s_rec[slot].z) vs.mask[i][block_g0 + slot] = s_ballot[i][slot];
+    }
     if (threadIdx.x < vs.n) {
         const uint32_t i = threadIdx.x;
         const uint32_t sum = (s_count[i][0] + s_count[i][1]) + (s_count[i][2] + s_count[i][3]);
@@ -1871,7 +2176,7 @@ hipError_t launch_classify_views(const SceneDev &s, const float4 *spheres, bool 
 
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st, const ViewConst *view_dev,
-                                  const uint8_t *view_flags, const uint32_t *useful, uint32_t *useful_report) {
+                                  const ViewHot2 *hot_dev, const uint8_t *view_flags, const uint32_t *useful, uint32_t *useful_report) {
     ViewSet vs;
     std::memset(&vs, 0, sizeof vs);
     vs.n = n_views;
@@ -1880,13 +2185,14 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
         vs.mask[i] = masks[i];
         vs.tile_counts[i] = tile_counts[i];
     }
+    fill_view_pairs(n_views, views, vs.hot);
     // two groups per wave: each group is evaluated n_views times, which hides the load latency that
     // the single-view kernel hides with four groups in flight
-    const uint32_t per_block = kWaves * 2;
+    const uint32_t per_block = kWaves * kViewsNG;
     const uint32_t grid = (uint32_t)((s.n_groups + per_block - 1) / per_block);
 #define MCULL_LAUNCH_VIEWS(NT_, VP_)                                                                                   \
-    hipLaunchKernelGGL((cull_mask_views_kernel<2, NT_, VP_>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, \
-                       s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs, view_dev,          \
+    hipLaunchKernelGGL((cull_mask_views_kernel<kViewsNG, NT_, VP_>), dim3(grid), dim3(kBlock), 0, st, s.cone_axis_w, s.centre_radius, \
+                       s.transforms, s.xf_scale, s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, vs, view_dev, hot_dev,  \
                        reinterpret_cast<const uint2 *>(view_flags), useful, useful_report)
     if (view_dev) {
         if (streaming) MCULL_LAUNCH_VIEWS(true, true);

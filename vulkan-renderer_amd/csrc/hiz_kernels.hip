@@ -197,12 +197,29 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
         if (!COPY && strips && t >= 192u) {
             const uint32_t l = t - 192u;
             const uint32_t sc = blockIdx.x * 8u + (l & 7u), br = blockIdx.y * 8u + (l >> 3);
-            if (sc < strips_w && br * 8u < strips_h) {
-                float mx = -__builtin_inff();
+            const uint32_t bw = strips_w, bh = (strips_h + 7u) >> 3;  // blocks per row / rows of blocks of the image
+            float mx = -__builtin_inff();  // stays so for a block outside the image
+            if (sc < bw && br < bh) {
 #pragma unroll
                 for (uint32_t r = 0; r < 8; r++)
                     mx = fmaxf(mx, strips[(size_t)min(br * 8u + r, strips_h - 1u) * strips_w + sc]);
-                strips[(size_t)strips_w * strips_h + (size_t)br * strips_w + sc] = mx;
+                strips[(size_t)strips_w * strips_h + (size_t)br * bw + sc] = mx;
+            }
+            // ... and three times more, 2 x 2 cells to one, with lane shuffles (every lane of the wave takes part): cells
+            // of 128, 256 and 512 pixels, each table behind the last, so that a screen rectangle of any size up to a
+            // quarter of the largest image is covered by a handful of cells (hiz_cell_table has the layout)
+            size_t off = (size_t)strips_w * strips_h + (size_t)bw * bh;
+            uint32_t cw = bw, ch = bh;
+#pragma unroll
+            for (uint32_t j = 1; j <= 3; j++) {
+                mx = fmaxf(mx, __shfl_xor(mx, 1 << (j - 1), 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 8 << (j - 1), 64));
+                cw = (cw + 1u) >> 1;
+                ch = (ch + 1u) >> 1;
+                const uint32_t m = (1u << j) - 1u;
+                if (((l & 7u) & m) == 0u && ((l >> 3) & m) == 0u && (sc >> j) < cw && (br >> j) < ch && sc < bw && br < bh)
+                    strips[off + (size_t)(br >> j) * cw + (sc >> j)] = mx;
+                off += (size_t)cw * ch;
             }
         }
         return;
@@ -440,12 +457,23 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
 // Does launch_hiz(mode) run the streaming pass on a w x h image, i.e. does it write `strips`: the largest depth of
 // every 64 x 8 strip of the image ((w + 63) / 64 per row, (h + 7) / 8 rows), followed by the largest depth of every
 // 64 x 64 block ((w + 63) / 64 per row, (h + 63) / 64 rows; written for the blocks inside the cover of the second
-// launch's tiles, hiz_block_cover) - hiz_strip_floats(w, h) floats in all?
+// launch's tiles), then of every cell of 128, 256 and 512 pixels (each table half the last in both directions, rounded
+// up) - hiz_strip_floats(w, h) floats in all?
 bool hiz_writes_strips(uint32_t w, uint32_t h, int mode) {
     return w >= 32 && h >= 32 && (mode == 3 || (mode == 0 && (uint64_t)w * h >= kStreamMinTexels));
 }
 
-size_t hiz_strip_floats(uint32_t w, uint32_t h) { return (size_t)((w + 63u) / 64u) * ((h + 7u) / 8u + (h + 63u) / 64u); }
+size_t hiz_strip_floats(uint32_t w, uint32_t h) {
+    const uint32_t sw = (w + 63u) / 64u;
+    size_t n = (size_t)sw * ((h + 7u) / 8u);
+    uint32_t cw = sw, ch = (h + 63u) / 64u;
+    for (int j = 0; j <= 3; j++) {  // cells of 64, 128, 256, 512 pixels
+        n += (size_t)cw * ch;
+        cw = (cw + 1u) >> 1;
+        ch = (ch + 1u) >> 1;
+    }
+    return n;
+}
 
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
                       const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st) {

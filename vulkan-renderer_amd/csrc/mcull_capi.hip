@@ -299,6 +299,11 @@ __global__ void derive_view_kernel(const mcull_globals *__restrict__ g, mcull::V
     *out = v;
 }
 
+// c->view_dev: MCULL_MAX_VIEWS + 1 ViewConst records (the last one is the rasteriser's), then the multi-view pass's
+// paired form of the first MCULL_MAX_VIEWS
+constexpr size_t kViewDevHotOff = ((MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst) + 255) & ~size_t(255);
+constexpr size_t kViewDevBytes = kViewDevHotOff + (MCULL_MAX_VIEWS / 2) * sizeof(mcull::ViewHot2);
+
 uint32_t level_count(uint32_t w, uint32_t h) {
     uint32_t m = w > h ? w : h, l = 0;
     while (m > 1) { m >>= 1; l++; }
@@ -1005,7 +1010,7 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
     if (g_dev) {
         if (pl.p.compaction != MCULL_COMPACT_ORDERED)
             return fail(c, MCULL_E_INVALID, "device-resident globals support ordered compaction only");
-        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        if (int rc = ensure(c, c->view_dev, kViewDevBytes)) return rc;
         view_dev = (const mcull::ViewConst *)c->view_dev.p;
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1146,9 +1151,10 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
     }
     const mcull::ViewConst *view_dev = nullptr;
     if (globals_dev) {
-        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        if (int rc = ensure(c, c->view_dev, kViewDevBytes)) return rc;
         view_dev = (const mcull::ViewConst *)c->view_dev.p;
     }
+    mcull::ViewHot2 *hot_dev = view_dev ? (mcull::ViewHot2 *)((char *)c->view_dev.p + kViewDevHotOff) : nullptr;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (view_dev) {
         for (uint32_t i = 0; i < n_views; i++) {
@@ -1156,6 +1162,7 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
                                (mcull::ViewConst *)c->view_dev.p + i);
             HIPCHK(c, hipGetLastError());
         }
+        HIPCHK(c, mcull::launch_pack_view_pairs(view_dev, n_views, hot_dev, c->stream));
     }
     if (pl[0].s.n_groups == 0) {
         for (uint32_t i = 0; i < n_views; i++) {
@@ -1213,7 +1220,7 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
                 useful_report = c->kept_dev + 1;
             }
         }
-        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev,
+        HIPCHK(c, mcull::launch_cull_mask_views(pl[0].s, n_views, vc, masks, counts, pl[0].streaming, c->stream, view_dev, hot_dev,
                                                 classify ? (const uint8_t *)c->view_flags.p : nullptr, useful_dev, useful_report));
         if (n_views == 1) {
             if (int rc = launch_ordered_tail(c, c->out[0], pl[0])) return rc;
@@ -1446,7 +1453,7 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     if (g) {
         mat4_mul(g->proj, g->view, vp);
     } else {
-        if (int rc = ensure(c, c->view_dev, (MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst))) return rc;
+        if (int rc = ensure(c, c->view_dev, kViewDevBytes)) return rc;
         view_dev = (const mcull::ViewConst *)c->view_dev.p + MCULL_MAX_VIEWS;  // the rasteriser's own record
     }
     if (!c->raster_scratch.p) {

@@ -41,6 +41,16 @@ struct ViewConst {
     unsigned long long *slow_pairs;
 };
 
+// What the frustum and cone tests need of TWO views, interleaved: element e of every pair belongs to the view in
+// slot 2p + e of a multi-view cull, so that one packed instruction serves both (cull_mask_views_kernel).
+struct ViewHot2 {
+    float frustum[5][4][2];
+    float cam[3][2];
+    uint32_t tests[2];
+    uint32_t force_exact[2];
+    uint32_t pad[2];  // 208 bytes
+};
+
 // Scene pointers of one cull launch.
 struct SceneDev {
     const float4 *cone_axis_w;    // {axis.xyz, coneW} per meshlet
@@ -79,8 +89,11 @@ bool needs_tile_offsets(uint64_t n_groups);  // the scatter pass wants one uint6
 // One pass over the scene for n_views views (ordered path only): views[i] -> masks[i], tile_counts[i].
 hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const ViewConst *const *views, uint64_t *const *masks,
                                   uint32_t *const *tile_counts, bool streaming, hipStream_t st,
-                                  const ViewConst *view_dev = nullptr, const uint8_t *view_flags = nullptr,
-                                  const uint32_t *useful = nullptr, uint32_t *useful_report = nullptr);
+                                  const ViewConst *view_dev = nullptr, const ViewHot2 *hot_dev = nullptr,
+                                  const uint8_t *view_flags = nullptr, const uint32_t *useful = nullptr,
+                                  uint32_t *useful_report = nullptr);
+// view_dev[0..n_views) (device memory) -> hot[0..MCULL_MAX_VIEWS / 2): what launch_cull_mask_views wants as hot_dev
+hipError_t launch_pack_view_pairs(const ViewConst *view_dev, uint32_t n_views, ViewHot2 *hot, hipStream_t st);
 // work: the instance pre-cull's work list (the pass then covers the listed groups only; the ballots of the others
 // must be zero already) or nullptr; kept_report: where the pass leaves the list's length (device pointer to
 // host-mapped memory) or nullptr
