@@ -611,6 +611,8 @@ def run_cull(env, workload):
                      "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % shard_note)
                      if multi else "single GPU"}
         if workload == "config5":
+            if r["vis_views"]:
+                extra_cfg["visible_per_view"] = [int(x) for x in r["vis_views"]]
             w, h = r["hiz_size"]
             algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
             algo_all += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])

@@ -1208,9 +1208,30 @@ __host__ __device__ inline uint32_t view_need_byte(uint32_t f, uint32_t tests) {
     return 8u | (tests & 7u & ~(((f & kInstInside) ? (uint32_t)MCULL_TEST_FRUSTUM : 0u) | ((f & kInstOpen) ? (uint32_t)MCULL_TEST_HIZ : 0u)));
 }
 
+// What is the same for every group of a multi-view cull, worked out once (on the host, or by pack_view_pairs_kernel).
+struct ViewsUniform {
+    uint32_t def_lo, def_hi;  // the need bytes (view_need_byte) of view slots 0-3 / 4-7 when no instance level has run
+    uint32_t exact_all;       // bit i: view i wants every pair through the IEEE expressions
+    uint32_t mixed;           // the views in use were not all asked for the same tests, or exact_all != 0
+};
+
+__host__ __device__ inline ViewsUniform views_uniform(uint32_t n_views, const uint32_t *tests, const uint32_t *force_exact) {
+    ViewsUniform u = {0u, 0u, 0u, 0u};
+    for (uint32_t i = 0; i < n_views; i++) {
+        const uint32_t b = 8u | (tests[i] & 7u);
+        if (i < 4u) u.def_lo |= b << (8u * i);
+        else u.def_hi |= b << (8u * (i - 4u));
+        if (force_exact[i]) u.exact_all |= 1u << i;
+        if ((tests[i] & 7u) != (tests[0] & 7u)) u.mixed = 1u;
+    }
+    if (u.exact_all) u.mixed = 1u;
+    return u;
+}
+
 struct ViewSet {
     ViewConst v[MCULL_MAX_VIEWS];
     ViewHot2 hot[MCULL_MAX_VIEWS / 2];
+    ViewsUniform uni;
     uint64_t *mask[MCULL_MAX_VIEWS];
     uint32_t *tile_counts[MCULL_MAX_VIEWS];
     uint32_t n;
@@ -1229,6 +1250,12 @@ void fill_view_pairs(uint32_t n_views, const ViewConst *const *views, ViewHot2 *
     }
 }
 
+ViewsUniform fill_views_uniform(uint32_t n_views, const ViewConst *const *views) {
+    uint32_t tests[MCULL_MAX_VIEWS] = {}, exact[MCULL_MAX_VIEWS] = {};
+    for (uint32_t i = 0; i < n_views; i++) { tests[i] = views[i]->tests; exact[i] = views[i]->force_exact; }
+    return views_uniform(n_views, tests, exact);
+}
+
 // The same from device-resident view constants (the *_device_globals calls): one thread per view slot.
 __global__ void pack_view_pairs_kernel(const ViewConst *__restrict__ view_dev, uint32_t n_views, ViewHot2 *__restrict__ hot) {
     const uint32_t i = threadIdx.x;
@@ -1241,6 +1268,11 @@ __global__ void pack_view_pairs_kernel(const ViewConst *__restrict__ view_dev, u
     for (int j = 0; j < 3; j++) h.cam[j][e] = real ? view_dev[i].cam[j] : 0.0f;
     h.tests[e] = real ? view_dev[i].tests : 0u;
     h.force_exact[e] = real ? view_dev[i].force_exact : 0u;
+    if (i == 0) {  // the uniforms go behind the pairs
+        uint32_t tests[MCULL_MAX_VIEWS], exact[MCULL_MAX_VIEWS];
+        for (uint32_t q = 0; q < MCULL_MAX_VIEWS; q++) { tests[q] = q < n_views ? view_dev[q].tests : 0u; exact[q] = q < n_views ? view_dev[q].force_exact : 0u; }
+        *reinterpret_cast<ViewsUniform *>(hot + MCULL_MAX_VIEWS / 2) = views_uniform(n_views, tests, exact);
+    }
 }
 
 hipError_t launch_pack_view_pairs(const ViewConst *view_dev, uint32_t n_views, ViewHot2 *hot, hipStream_t st) {
@@ -1436,34 +1468,49 @@ struct ViewsGroup {
 
 // Frustum and cone tests of group K of the wave against the views 2P and 2P + 1; the survivors' ballots go to lanes
 // (2P) * NG + K and (2P + 1) * NG + K of blo / bhi.
+// A test the instance level has settled for the instance ("no meshlet is rejected") may still be run on its meshlets -
+// it rejects none - so a block that runs for one view of the pair applies its result to both, unless the views were not
+// ASKED for the same tests or one of them wants the IEEE expressions throughout (`mixed`, rare: then every step looks
+// at the views' own bits).
 template <int P, int K, int NG, typename AxisFn>
 __device__ __forceinline__ void views_pair_step(const ViewsGroup &g, const ViewHot2 *__restrict__ hot, const f2v *__restrict__ cam,
-                                                uint32_t exact_all, const ViewConst *__restrict__ views, AxisFn &&exact_axis,
-                                                uint32_t &blo, uint32_t &bhi) {
+                                                uint32_t mixed, uint32_t asked, uint32_t exact_all,
+                                                const ViewConst *__restrict__ views, AxisFn &&exact_axis, uint32_t &blo, uint32_t &bhi) {
     const uint32_t nb = (P < 2 ? g.nb_lo : g.nb_hi) >> (16 * (P & 1));  // bytes 2P and 2P + 1 of the instance's eight
     uint64_t live0 = (nb & 8u) ? g.in : 0ull, live1 = (nb & 0x800u) ? g.in : 0ull;
-    if ((nb & 0x0101u) && (live0 | live1)) {
-        uint64_t c0, c1;
-        frustum2(hot, g.wc, c0, c1);
-        if (nb & 0x0001u) live0 &= ~c0;
-        if (nb & 0x0100u) live1 &= ~c1;
-    }
-    if ((nb & 0x0202u) && (live0 | live1)) {
-        const f2v camx = cam[0], camy = cam[1], camz = cam[2];
-        uint64_t c0, c1, sure0, sure1;
-        cone2_fast(camx, camy, camz, g.wc, g.cp, c0, c1, sure0, sure1);
-        if (exact_all & (1u << (2 * P))) sure0 = 0;
-        if (exact_all & (2u << (2 * P))) sure1 = 0;
-        const uint64_t slow0 = (nb & 0x0002u) ? live0 & ~sure0 : 0ull, slow1 = (nb & 0x0200u) ? live1 & ~sure1 : 0ull;
-        if (slow0 | slow1) {  // rare: the IEEE expression, in functions of their own so that their registers are not the kernel's
-            const float4 wa = exact_axis();
-            if (slow0) c0 = (c0 & ~slow0) | (__ballot(cone_exact(wa, g.wc, camx.x, camy.x, camz.x)) & slow0);
-            if (slow1) c1 = (c1 & ~slow1) | (__ballot(cone_exact(wa, g.wc, camx.y, camy.y, camz.y)) & slow1);
-            if (slow0) note_slow(views[2 * P], lane_of(slow0));
-            if (slow1) note_slow(views[2 * P + 1], lane_of(slow1));
+    if (live0 | live1) {
+        const uint32_t ask = mixed ? asked >> (16 * (P & 1)) : nb | (nb >> 8) | (nb << 8);  // the tests each view may be given
+        if (nb & 0x0101u) {
+            uint64_t c0, c1;
+            frustum2(hot, g.wc, c0, c1);
+            if (mixed) {
+                if (!(ask & 0x0001u)) c0 = 0;
+                if (!(ask & 0x0100u)) c1 = 0;
+            }
+            live0 &= ~c0;
+            live1 &= ~c1;
         }
-        if (nb & 0x0002u) live0 &= ~c0;
-        if (nb & 0x0200u) live1 &= ~c1;
+        if ((nb & 0x0202u) && (live0 | live1)) {
+            const f2v camx = cam[0], camy = cam[1], camz = cam[2];
+            uint64_t c0, c1, sure0, sure1;
+            cone2_fast(camx, camy, camz, g.wc, g.cp, c0, c1, sure0, sure1);
+            uint64_t slow0 = live0 & ~sure0, slow1 = live1 & ~sure1;
+            if (mixed) {
+                if (!(ask & 0x0002u)) c0 = slow0 = 0;
+                if (!(ask & 0x0200u)) c1 = slow1 = 0;
+                if ((exact_all & (1u << (2 * P))) && (ask & 0x0002u)) slow0 = live0;
+                if ((exact_all & (2u << (2 * P))) && (ask & 0x0200u)) slow1 = live1;  // (bit i of exact_all: view i)
+            }
+            if (slow0 | slow1) {  // rare: the IEEE expression, in functions of their own so that their registers are not the kernel's
+                const float4 wa = exact_axis();
+                if (slow0) c0 = (c0 & ~slow0) | (__ballot(cone_exact(wa, g.wc, camx.x, camy.x, camz.x)) & slow0);
+                if (slow1) c1 = (c1 & ~slow1) | (__ballot(cone_exact(wa, g.wc, camx.y, camy.y, camz.y)) & slow1);
+                if (slow0) note_slow(views[2 * P], lane_of(slow0));
+                if (slow1) note_slow(views[2 * P + 1], lane_of(slow1));
+            }
+            live0 &= ~c0;
+            live1 &= ~c1;
+        }
     }
     set_lane<(2 * P) * NG + K>(blo, (uint32_t)live0);
     set_lane<(2 * P) * NG + K>(bhi, (uint32_t)(live0 >> 32));
@@ -1520,20 +1567,9 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
         a[k] = load_bounds<NT>(cone_axis_w + id);
         c[k] = load_bounds<NT>(centre_radius + id);
     }
-    // without an instance level every view slot in use needs all of its tests; which views want every pair through
-    // the IEEE expressions (two bits per pair of views)
-    uint32_t def_lo = 0, def_hi = 0, exact_all = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < MCULL_MAX_VIEWS / 2; q++) {
-        const ViewHot2 *hot = VP ? hot_dev + q : vs.hot + q;
-        const uint32_t two = (2u * q < vs.n ? (8u | (hot->tests[0] & 7u)) : 0u) | ((2u * q + 1u < vs.n ? (8u | (hot->tests[1] & 7u)) : 0u) << 8);
-        if (q < 2u) def_lo |= two << (16u * q);
-        else def_hi |= two << (16u * (q - 2u));
-        exact_all |= ((hot->force_exact[0] ? 1u : 0u) | (hot->force_exact[1] ? 2u : 0u)) << (2u * q);
-    }
-    def_lo = __builtin_amdgcn_readfirstlane(def_lo);  // (uniform already; loads from hot_dev come back in vector registers)
-    def_hi = __builtin_amdgcn_readfirstlane(def_hi);
-    exact_all = __builtin_amdgcn_readfirstlane(exact_all);
+    const ViewsUniform *up = VP ? reinterpret_cast<const ViewsUniform *>(hot_dev + MCULL_MAX_VIEWS / 2) : &vs.uni;
+    const uint32_t def_lo = __builtin_amdgcn_readfirstlane(up->def_lo), def_hi = __builtin_amdgcn_readfirstlane(up->def_hi);
+    const uint32_t exact_all = __builtin_amdgcn_readfirstlane(up->exact_all), mixed = __builtin_amdgcn_readfirstlane(up->mixed);
     __syncthreads();
     // what does not depend on the view, once per group
     ViewsGroup grp[NG];
@@ -1577,7 +1613,7 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
                     const uint32_t last = r.z ? r.z - 1u : 0u;
                     return world_axis_again(transforms + (size_t)r.x * 4, cone_axis_w + r.y + (lane < last ? lane : last));
                 };
-                views_pair_step<Pc, Kc, NG>(grp[Kc], hots + Pc, s_cam[Pc], exact_all, views, exact_axis, blo, bhi);
+                views_pair_step<Pc, Kc, NG>(grp[Kc], hots + Pc, s_cam[Pc], mixed, Pc < 2 ? def_lo : def_hi, exact_all, views, exact_axis, blo, bhi);
             }
         };
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
@@ -1587,18 +1623,26 @@ __global__ __launch_bounds__(kBlock) void cull_mask_views_kernel(
     do_pair(std::integral_constant<int, 2>{}); do_pair(std::integral_constant<int, 3>{});
     // ---- the occlusion test of the (view, group) combinations that still want it, on the ballots gathered so far
     if (any_hiz) {
-        for (uint32_t i = 0; i < vs.n; i++) {
-            const ViewConst &v = views[i];
+        // Only the (view, group) combinations that still want the test are visited: bit 2 of every need byte, gathered
+        // into one word (bit 8 * view + group).  The test itself is compiled ONCE, whichever
+        // group it serves: the kernel has to fit the instruction cache.
+        uint64_t want = 0;
 #pragma unroll
-            for (int k = 0; k < NG; k++) {
-                const uint32_t nb = ((i < 4u ? grp[k].nb_lo : grp[k].nb_hi) >> (8u * (i & 3u)));
-                if (!(nb & MCULL_TEST_HIZ)) continue;
-                const uint32_t l = i * NG + k;
-                const uint64_t live = ((uint64_t)lane_u32(bhi, l) << 32) | lane_u32(blo, l);
-                if (!live) continue;
-                const uint64_t left = live & ~__ballot(occlusion1(v, grp[k].wc, lane_of(live)));
-                if (lane == l) { blo = (uint32_t)left; bhi = (uint32_t)(left >> 32); }
-            }
+        for (int k = 0; k < NG; k++)
+            want |= ((uint64_t)((grp[k].nb_lo >> 2) & 0x01010101u) | ((uint64_t)((grp[k].nb_hi >> 2) & 0x01010101u) << 32)) << k;
+        while (want) {
+            const uint32_t pos = (uint32_t)__builtin_ctzll(want);
+            want &= want - 1ull;
+            const uint32_t i = pos >> 3, k = pos & 7u;
+            const uint32_t l = i * NG + k;
+            const uint64_t live = ((uint64_t)lane_u32(bhi, l) << 32) | lane_u32(blo, l);
+            if (!live) continue;
+            float4 w = grp[0].wc;
+#pragma unroll
+            for (int q = 1; q < NG; q++)
+                if (k == (uint32_t)q) w = grp[q].wc;
+            const uint64_t left = live & ~__ballot(occlusion1(views[i], w, lane_of(live)));
+            if (lane == l) { blo = (uint32_t)left; bhi = (uint32_t)(left >> 32); }
         }
     }
     // ---- ballots and counts: lane view * NG + group owns one of each
@@ -2186,6 +2230,7 @@ hipError_t launch_cull_mask_views(const SceneDev &s, uint32_t n_views, const Vie
         vs.tile_counts[i] = tile_counts[i];
     }
     fill_view_pairs(n_views, views, vs.hot);
+    vs.uni = fill_views_uniform(n_views, views);
     // two groups per wave: each group is evaluated n_views times, which hides the load latency that
     // the single-view kernel hides with four groups in flight
     const uint32_t per_block = kWaves * kViewsNG;

@@ -302,7 +302,7 @@ __global__ void derive_view_kernel(const mcull_globals *__restrict__ g, mcull::V
 // c->view_dev: MCULL_MAX_VIEWS + 1 ViewConst records (the last one is the rasteriser's), then the multi-view pass's
 // paired form of the first MCULL_MAX_VIEWS
 constexpr size_t kViewDevHotOff = ((MCULL_MAX_VIEWS + 1) * sizeof(mcull::ViewConst) + 255) & ~size_t(255);
-constexpr size_t kViewDevBytes = kViewDevHotOff + (MCULL_MAX_VIEWS / 2) * sizeof(mcull::ViewHot2);
+constexpr size_t kViewDevBytes = kViewDevHotOff + (MCULL_MAX_VIEWS / 2) * sizeof(mcull::ViewHot2) + 256;  // + the pass's uniforms
 
 uint32_t level_count(uint32_t w, uint32_t h) {
     uint32_t m = w > h ? w : h, l = 0;
