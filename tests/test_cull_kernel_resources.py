@@ -52,3 +52,15 @@ def test_streamed_mask_pass_keeps_seven_waves_per_simd(usage):
     for n in name:
         u = usage[n]
         assert int(u["VGPRs"]) <= 72 and int(u["Occupancy"]) >= 7 and u["SGPRs Spill"] == "0", (n, u)
+
+
+def test_multi_view_pass_keeps_eight_waves_per_simd(usage):
+    """The multi-view mask pass is bound by instruction issue and by the latency of its two dependent loads: eight waves
+    per SIMD (64 vector registers) are what hides both.  (Its by-value view set must never have its address taken -
+    a pointer to one of its members handed to a function call once put the whole 3 KB into scratch memory and the pass
+    ran thirty times slower; the scratch assertion above covers that.)"""
+    name = [k for k in usage if "cull_mask_views_kernel" in k]
+    assert len(name) == 4, name
+    for n in name:
+        u = usage[n]
+        assert int(u["VGPRs"]) <= 64 and int(u["Occupancy"]) == 8 and u["SGPRs Spill"] == "0" and u["ScratchSize"] == "0", (n, u)

@@ -673,7 +673,7 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
     for (int k = 0; k < 4; k++) {
         const float m0 = v.vp[k], m1 = v.vp[4 + k], m2 = v.vp[8 + k], m3 = v.vp[12 + k];
         c[k] = ((m0 * wx + m1 * wy) + m2 * wz) + m3;
-        const float len = __builtin_amdgcn_sqrtf((m0 * m0 + m1 * m1) + m2 * m2) * 1.0001f;  // 1 ulp, far inside the factor
+        const float len = v.vp_row_len[k];  // >= |row k of the linear part|
         const float mag = ((fabsf(m0) * (fabsf(wx) + rho) + fabsf(m1) * (fabsf(wy) + rho)) + fabsf(m2) * (fabsf(wz) + rho)) + fabsf(m3);
         e[k] = len * rho * 1.0001f + mag * 1.52587890625e-5f;  // 2^-16: a thousand times the roundoff of both evaluations
     }
@@ -831,7 +831,7 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
 #pragma unroll
         for (int p = 0; p < 5; p++) {
             const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2], d = v.frustum[p][3];
-            const float nlen = fmaxf(__builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
+            const float nlen = v.plane_len[p];  // >= max(|n|, 1)
             const float reach = nlen * F * R;
             const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
             const float base = ((nx * wx + ny * wy) + nz * wz) + d, margin = A * 1.52587890625e-5f;  // 2^-16

@@ -296,6 +296,7 @@ __global__ void derive_view_kernel(const mcull_globals *__restrict__ g, mcull::V
     mat4_mul(g->proj, g->view, v.vp);
     camera_position(g->view, v.cam);
     v.proj11 = g->proj[5];
+    mcull::view_derive_bounds(v);
     *out = v;
 }
 
@@ -797,6 +798,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
         mat4_mul(g->proj, g->view, v.vp);
         camera_position(g->view, v.cam);
         v.proj11 = g->proj[5];
+        mcull::view_derive_bounds(v);
     }
     v.tests = p.tests;
     v.uniform_count = plan->uniform_count;

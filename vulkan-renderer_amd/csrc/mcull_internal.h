@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <vector>
 #include <stdint.h>
 
@@ -39,7 +40,24 @@ struct ViewConst {
     // tests); slow_pairs != nullptr counts the pairs that had to leave the fast forms
     uint32_t force_exact;
     unsigned long long *slow_pairs;
+    // what the instance and group levels need of the view alone (view_derive_bounds): an upper bound of each plane
+    // normal's length, not below 1, and of the length of each row of proj*view's linear part - evaluated once per view
+    // instead of once per instance and view
+    float plane_len[5];
+    float vp_row_len[4];
 };
+
+// plane_len / vp_row_len from frustum / vp.  The factors cover the rounding of the square root on either side.
+__host__ __device__ inline void view_derive_bounds(ViewConst &v) {
+    for (int p = 0; p < 5; p++) {
+        const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2];
+        v.plane_len[p] = fmaxf(sqrtf((nx * nx + ny * ny) + nz * nz) * 1.00001f, 1.0f);
+    }
+    for (int k = 0; k < 4; k++) {
+        const float m0 = v.vp[k], m1 = v.vp[4 + k], m2 = v.vp[8 + k];
+        v.vp_row_len[k] = sqrtf((m0 * m0 + m1 * m1) + m2 * m2) * 1.0001f;
+    }
+}
 
 // What the frustum and cone tests need of TWO views, interleaved: element e of every pair belongs to the view in
 // slot 2p + e of a multi-view cull, so that one packed instruction serves both (cull_mask_views_kernel).
