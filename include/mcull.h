@@ -149,8 +149,8 @@ typedef struct mcull_task_payload {
  * The occlusion half relies on the pyramid being the min-reduction of its own level 0 (mcull_hiz_build's
  * output, not a buffer edited afterwards), and on it holding no NaN: min(x, y) = y < x ? y : x can drop a NaN
  * on the way up, so a coarse texel then says nothing about the finer ones.  mcull_hiz_build notices a NaN in
- * the depth image; the occlusion half stays off for that view slot from then on (until the context is
- * destroyed), the results are unaffected.
+ * the depth image; the occlusion half is then off for that view slot until the slot's pyramid is built again
+ * from an image without one (every build re-evaluates it, inside its own launches).  The results are unaffected.
  * The same bounds also show when an instance lies inside all five planes, or in front of everything the
  * pyramid holds under it (largest depth of the image region, from two small tables mcull_hiz_build leaves
  * behind for images from 6 M texels on): the per-meshlet pass then leaves that test out for the instance's

@@ -154,7 +154,8 @@ def test_uniform_scene_and_device_globals(mc, O, H, pctx, kitten):
 
 def test_a_nan_in_the_depth_image_switches_the_occlusion_level_off(mc, O, H, pctx):
     """min(x, y) = y < x ? y : x can drop a NaN between levels, so a coarse texel says nothing about the fine
-    ones under it: a slot that has seen a NaN keeps the instance-level occlusion test off."""
+    ones under it: a slot whose pyramid was built from an image with a NaN runs without the instance-level
+    occlusion test - until the slot is built again from an image without one."""
     w, h = 512, 512
     cone, sphere, t, off, cnt = scene(H, 800, 32, seed=55, extent=18.0)
     depth = np.full((h, w), 0.4, dtype="<f4")  # everything behind a near wall ...
@@ -170,17 +171,54 @@ def test_a_nan_in_the_depth_image_switches_the_occlusion_level_off(mc, O, H, pct
     pctx.hiz_build(depth, view=1)
     marked, hidden, ref = run(mc, O, pctx, g, O.View(g, O.hiz_build(depth), w, h), cone, sphere, t, off, cnt, 4, hiz_view=1)
     assert marked > 0.5 * hidden > 0
-    # the wall with NaN holes in slot 0: identical to the oracle, nothing dropped by occlusion
+    clean_marked = marked
     with np.errstate(all="ignore"):
-        pctx.hiz_build(holes, view=0)
-        marked, hidden, ref = run(mc, O, pctx, g, O.View(g, O.hiz_build(holes), w, h), cone, sphere, t, off, cnt, 4, hiz_view=0)
-        assert marked == 0 and ref.total > 0
-        # slot 0 stays off after a clean rebuild; slot 1 is unaffected
-        pctx.hiz_build(depth, view=0)
-        marked, _, _ = run(mc, O, pctx, g, O.View(g, O.hiz_build(depth), w, h), cone, sphere, t, off, cnt, 4, hiz_view=0)
-        assert marked == 0
-        marked, _, _ = run(mc, O, pctx, g, O.View(g, O.hiz_build(depth), w, h), cone, sphere, t, off, cnt, 4, hiz_view=1)
-        assert marked > 0
+        for _ in range(2):  # NaN image -> off, clean rebuild -> on again, twice over
+            # the wall with NaN holes in slot 0: identical to the oracle, nothing dropped by occlusion
+            pctx.hiz_build(holes, view=0)
+            marked, hidden, ref = run(mc, O, pctx, g, O.View(g, O.hiz_build(holes), w, h), cone, sphere, t, off, cnt, 4, hiz_view=0)
+            assert marked == 0 and ref.total > 0
+            # slot 1 is unaffected
+            marked, _, _ = run(mc, O, pctx, g, O.View(g, O.hiz_build(depth), w, h), cone, sphere, t, off, cnt, 4, hiz_view=1)
+            assert marked == clean_marked
+            # a clean rebuild of slot 0: the word describes the image the pyramid was LAST built from
+            pctx.hiz_build(depth, view=0)
+            marked, _, _ = run(mc, O, pctx, g, O.View(g, O.hiz_build(depth), w, h), cone, sphere, t, off, cnt, 4, hiz_view=0)
+            assert marked == clean_marked
+
+
+@pytest.mark.parametrize("size", [(64, 48), (100, 100), (3, 200), (512, 512), (1200, 700)])
+@pytest.mark.parametrize("scheme", ["MCULL_HIZ_TILES", "MCULL_HIZ_STREAM", "MCULL_HIZ_SINGLE_LAUNCH", None])
+def test_the_nan_word_follows_the_last_build_in_every_pyramid_scheme(mc, O, H, monkeypatch, size, scheme):
+    """Every scheme and every image size class (one workgroup, tiles without a second launch, tiles + top levels,
+    streaming pass) must publish the word from inside its own launches: a NaN image, then a clean one, then a NaN one."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_PRECULL_ADAPTIVE", "0")
+    if scheme:
+        monkeypatch.setenv(scheme, "1")
+    w, h = size
+    with mc.Context(0) as ctx:
+        cone, sphere, t, off, cnt = scene(H, 300, 16, seed=5, extent=10.0)
+        ctx.upload_bounds_soa(cone, sphere)
+        ctx.upload_transforms(t)
+        ctx.set_instance_ranges(off, cnt)
+        g = H.create_globals(eye=(18.0, 16.0, 14.0), width=w, height=h, flip_y=False)
+        wall = np.full((h, w), 0.5, dtype="<f4")
+        bad = wall.copy()
+        bad[h // 2, w // 3] = np.nan
+        ref = O.cull_scene(O.View(g, O.hiz_build(wall), w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=4)
+        seen = []
+        with np.errstate(all="ignore"):
+            for img in (bad, wall, bad, wall):
+                ctx.hiz_build(img, view=3)
+                ctx.cull(g, tests=4, hiz_view=3, write_mask=True)
+                seen.append(ctx.precull_stats()[0])
+                if img is wall:
+                    compare(mc, ctx, ref, len(t))
+        assert seen[0] == 0 and seen[2] == 0, seen
+        assert seen[1] == seen[3], seen
+        if min(w, h) >= 48:  # (a sliver of an image offers no rectangle to prove anything with)
+            assert seen[1] > 0, seen
 
 
 def test_negative_radii_and_hostile_transforms(mc, O, H, pctx):

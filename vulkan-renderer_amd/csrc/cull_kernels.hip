@@ -654,8 +654,8 @@ __host__ __device__ inline size_t work_rec_offset_words(uint64_t units) { return
 // levels drop the odd last column and row of their source, so the rectangle must lie inside level k's cover).
 // The instance is hidden when nz_ub < dmin - 0.05f.  That holds as long as no texel is a NaN: the reduction
 // min(x, y) = y < x ? y : x can drop one, and the fine level would then answer "visible" where the coarse one
-// does not.  Word 48 of a pyramid's level table is set by the pyramid kernels when the depth image holds a NaN
-// (and stays set); the instance test is then off for that pyramid.  Anything non-finite or out of range among
+// does not.  Word 48 of a pyramid's level table says whether the depth image it was last built from held a NaN;
+// the instance test is then off for that pyramid.  Anything non-finite or out of range among
 // the intermediate values fails a comparison below, and the instance is not marked.
 // The same intervals also prove the opposite for instances in the open (kInstOpen): every texel a meshlet can
 // select is a minimum over texels of the rectangle, hence not ABOVE the largest depth of the 64 x 8 strips of the

@@ -14,9 +14,11 @@
 // that finish last (two tiers of atomic tickets, write-through stores + agent-scope loads).  min() is
 // written as (y < x ? y : x), GLSL's definition, so the result is bit-identical to the
 // level-by-level evaluation for every input including NaN and signed zero.
-// The kernels that read the depth image also report a NaN in it (`nan_seen`, set to 1, never cleared here):
-// that reduction can drop a NaN on the way up, so a coarse level does not bound the finer ones from below
-// when one is present, which the instance-level occlusion test of the cull needs to know.
+// The kernels that read the depth image also report a NaN in it: that reduction can drop a NaN on the way up, so a
+// coarse level does not bound the finer ones from below when one is present, which the instance-level occlusion test
+// of the cull needs to know.  `nan_seen` points at two words: the kernels that read the image set word 1 when they
+// meet a NaN, and the LAST launch of every build moves it to word 0 - what the culls read - and clears it
+// (publish_nan_word), so word 0 always describes the image the pyramid was last built from.
 #include "mcull_internal.h"
 
 namespace mcull {
@@ -27,6 +29,13 @@ constexpr uint32_t kMaxSinglePass = 8192;  // 128x128 tiles = 16x16 ticket group
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y : x; }
+
+// By one thread of a launch that starts after every kernel that reads the depth image of this build has finished
+// (stream order), or by a workgroup's thread 0 after a barrier behind its own reads.
+__device__ __forceinline__ void publish_nan_word(uint32_t *__restrict__ nan_seen) {
+    nan_seen[0] = __hip_atomic_load(nan_seen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nan_seen[1] = 0u;
+}
 __device__ __forceinline__ float min4(float d0, float d1, float d2, float d3) {
     return glsl_min(glsl_min(d0, d1), glsl_min(d2, d3));  // shader.comp:28
 }
@@ -57,17 +66,19 @@ __device__ void reduce_levels_from_global(float *__restrict__ pyr, const uint32_
 __global__ __launch_bounds__(kBlock) void hiz_generic_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                              float *__restrict__ pyr,
                                                              const uint32_t *__restrict__ tbl, uint32_t levels,
-                                                             uint32_t k_begin, uint32_t *__restrict__ nan_seen) {
+                                                             uint32_t k_begin, uint32_t *__restrict__ nan_seen, uint32_t publish) {
     if (k_begin == 0) {
         const size_t n = (size_t)w * h;
         for (size_t i = threadIdx.x; i < n; i += kBlock) {
             const float d = depth[i];
             pyr[i] = d;  // shader.comp:19-21
-            if (d != d) *nan_seen = 1u;
+            if (d != d) nan_seen[1] = 1u;
         }
         __syncthreads();
+        if (threadIdx.x == 0) publish_nan_word(nan_seen);
         reduce_levels_from_global(pyr, tbl, 1, levels);
     } else {
+        if (publish && threadIdx.x == 0) publish_nan_word(nan_seen);  // the launches that read the depth image have finished
         reduce_levels_from_global(pyr, tbl, k_begin, levels);
     }
 }
@@ -149,7 +160,9 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int c = 0; c < 4; c++) nan |= p[r][c] != p[r][c];
-        if (nan) *nan_seen = 1u;
+        if (nan) nan_seen[1] = 1u;
+    } else if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+        publish_nan_word(nan_seen);  // second launch of the streaming scheme: the pass over the depth image has finished
     }
     if (levels == 1) return;
 
@@ -338,7 +351,7 @@ __device__ __forceinline__ float hiz_rows8(const float *__restrict__ depth, uint
         for (uint32_t r = 0; r < 8; r++)
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) nan |= p[r][c] != p[r][c];
-        if (nan) *nan_seen = 1u;
+        if (nan) nan_seen[1] = 1u;
     }
     // ---- the LARGEST depth of each 64 x 8 strip of the image (16 lanes wide, this wave's 8 rows): what the
     // occlusion test looks at before it reads a texel of levels 0-3, whose footprint lies inside one strip -
@@ -425,6 +438,13 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
     const dim3 grid((w + kTile - 1) / kTile, (h + kTile - 1) / kTile);
     const bool vec = (w % 4u) == 0u && (reinterpret_cast<uintptr_t>(src) & 15u) == 0u &&
                      (!COPY || (reinterpret_cast<uintptr_t>(pyramid) & 15u) == 0u);
+    // COPY: this launch reads the depth image, so a launch behind it publishes the NaN word (the one-workgroup kernel,
+    // which has levels to reduce only when the tiles leave some)
+    auto publish = [&](uint32_t k_begin) {
+        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, src, w, h, pyramid, level_table, levels, k_begin, nan_seen,
+                           COPY ? 1u : 0u);
+        return hipGetLastError();
+    };
     if (single_pass && levels > 7 && w <= kMaxSinglePass && h <= kMaxSinglePass) {
         if (vec)
             hipLaunchKernelGGL((hiz_tile_kernel<true, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
@@ -432,7 +452,8 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
         else
             hipLaunchKernelGGL((hiz_tile_kernel<false, true, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
                                level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
-        return hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        return (e != hipSuccess || !COPY) ? e : publish(levels);
     }
     if (vec)
         hipLaunchKernelGGL((hiz_tile_kernel<true, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
@@ -440,12 +461,9 @@ static hipError_t launch_tiles(const float *src, uint32_t w, uint32_t h, float *
     else
         hipLaunchKernelGGL((hiz_tile_kernel<false, false, COPY>), grid, dim3(kBlock), 0, st, src, w, h, pyramid,
                            level_table, levels, counter, nan_seen, strips, strips_w, strips_h);
-    hipError_t e = hipGetLastError();
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (levels > 7) {
-        hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, src, w, h, pyramid, level_table, levels, 7u, nan_seen);
-        e = hipGetLastError();
-    }
+    if (levels > 7 || COPY) return publish(levels > 7 ? 7u : levels);
     return e;
 }
 
@@ -479,7 +497,7 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
                       const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st) {
     if (w < 4 || h < 4) {
         hipLaunchKernelGGL(hiz_generic_kernel, dim3(1), dim3(kBlock), 0, st, depth, w, h, pyramid, level_table, levels,
-                           0u, nan_seen);
+                           0u, nan_seen, 1u);
         return hipGetLastError();
     }
     // level 3 must itself be at least 4x4, the tiled kernel's own precondition

@@ -184,8 +184,9 @@ hipError_t launch_depth_raster(const mcull_visible *list, const uint64_t *total,
 size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs as `scratch`
 
 // `counter`: kHizCounterBytes of ticket words, zero before the first launch (each launch leaves them zero).
-// `level_table`: kHizTableWords uint32 - 3 x 16 level widths / heights / offsets, then word kHizNanWord, which the
-// launch sets to 1 when the depth image holds a NaN and never clears (`nan_seen` points at it).
+// `level_table`: kHizTableWords uint32 - 3 x 16 level widths / heights / offsets, then word kHizNanWord: 1 when the depth
+// image of the LAST build held a NaN, else 0 (`nan_seen` points at it; the word behind it is the build's scratch, zero
+// between builds).
 constexpr size_t kHizCounterBytes = 2048;
 constexpr uint32_t kHizTableWords = 64, kHizNanWord = 48;
 // `strips` (optional): hiz_strip_floats(w, h) floats - the largest depth of every 64 x 8 strip of the image, row by row
