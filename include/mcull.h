@@ -131,9 +131,15 @@ typedef struct mcull_task_payload {
  * EXT_GROUPS: the three-word VkDrawMeshTasksIndirectCommandEXT form {groupCountX = visible_i,
  *   groupCountY = 1, groupCountZ = 1} (12 bytes) for a frontend on VK_EXT_mesh_shader; that record
  *   has no firstTask, so the mesh stage reads list[first_task[gl_DrawID] + gl_WorkGroupID.x] with
- *   first_task from mcull_cull_result.  The reference itself only uses the NV form. */
+ *   first_task from mcull_cull_result.  The reference itself only uses the NV form.
+ * NV_TASK_GROUPS: the NV record with the reference's own granularity, taskCount = ceil(visible_i / 32) task
+ *   workgroups of 32 (Engine.cpp:1475-1483 launches ceil(meshletCount / 32) per draw, shader.task:12), for a frontend
+ *   that keeps a pass-through task stage: task workgroup w of draw i forwards list[firstTask_i + 32 w + lane] while
+ *   32 w + lane < visible_i, where firstTask_i is the draw's offset in the list (the same value as in NV_MESHLETS
+ *   records) and visible_i = first_task[i + 1] - first_task[i] from mcull_cull_result.  8 bytes. */
 #define MCULL_CMD_NV_MESHLETS 0
 #define MCULL_CMD_EXT_GROUPS 1
+#define MCULL_CMD_NV_TASK_GROUPS 2
 
 /* mcull_cull_params.flags.
  * Ordered single-view culls (mcull_cull, mcull_cull_device_globals) first test ONE enclosing sphere per
@@ -182,7 +188,7 @@ typedef struct mcull_cull_params {
     uint32_t tests;          /* MCULL_TEST_* bits                                      */
     uint32_t compaction;     /* MCULL_COMPACT_*                                        */
     uint32_t hiz_view;       /* which pyramid slot the Hi-Z test samples               */
-    uint32_t cmd_form;       /* MCULL_CMD_NV_MESHLETS or MCULL_CMD_EXT_GROUPS          */
+    uint32_t cmd_form;       /* MCULL_CMD_NV_MESHLETS, _EXT_GROUPS or _NV_TASK_GROUPS  */
     uint32_t cmd_stride;     /* bytes between commands; 0 -> the record size (8 / 12)  */
     uint32_t cmd_offset;     /* byte offset of the command in a record; 28/20 = DrawIndirect */
     uint32_t write_mask;     /* non-zero: keep the 1-bit-per-pair visibility mask      */
@@ -301,9 +307,12 @@ int mcull_cull(mcull_ctx *ctx, const mcull_globals *globals, const mcull_cull_pa
  * (visibility ballots, tile counters, per-instance list offsets) live in a static device array of
  * MCULL_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
  * Limits: at most MCULL_STATIC_MAX_GROUPS 64-meshlet groups (134 M meshlet-instances) and
- * MCULL_STATIC_MAX_INSTANCES instances, else MCULL_E_CAPACITY.  All contexts of one GPU share that array:
- * calls that overlap on one GPU (two streams, two threads) race; result->mask / first_task point into it
- * and stay valid only until the next mcull_cull_static on that GPU.  The context's stored result (what the
+ * MCULL_STATIC_MAX_INSTANCES instances, else MCULL_E_CAPACITY.  All contexts of one GPU share that array, so
+ * calls must not overlap on one GPU: a call made while an earlier one on ANOTHER stream of the same GPU has not
+ * finished returns MCULL_E_STATE and launches nothing (the guard is a recorded event; it cannot see calls made
+ * under stream capture, whose overlap is the caller's to exclude).  params->write_mask and
+ * MCULL_CULL_COUNT_SLOW_PAIRS are not supported here (MCULL_E_INVALID).  result->mask / first_task point into
+ * the array and stay valid only until the next mcull_cull_static on that GPU.  The context's stored result (what the
  * download / rebase / payload / rasterise calls refer to) is left untouched. */
 #define MCULL_STATIC_MAX_GROUPS 2097152ull
 #define MCULL_STATIC_MAX_INSTANCES 1048576ull
@@ -374,8 +383,8 @@ int mcull_download_mask(mcull_ctx *ctx, uint64_t *out, uint64_t words);
  * IEEE expressions, counted once per test that sent them there.  Synchronous.  No reference counterpart. */
 int mcull_slow_path_pairs(mcull_ctx *ctx, uint64_t *pairs);
 
-/* What the instance pre-cull of the last cull removed (synchronous; one small counting kernel, run on
- * request only).  *marked = instances marked as certainly outside the frustum or certainly occluded (scenes
+/* What the instance pre-cull of the last cull removed (synchronous: reads the length of the work list the
+ * pre-cull left behind).  *marked = instances marked as certainly outside the frustum or certainly occluded (scenes
  * without instance ranges) or 64-meshlet groups of such instances (scenes with ranges: *per_group != 0);
  * *tested = how many instances / groups there were.  0 / 0 when the pre-cull did not run (frustum and occlusion
  * tests both off, switched off or backed off, scene below 65536 groups, unordered compaction, one of several

@@ -318,6 +318,47 @@ def test_empty_and_degenerate_scenes(mc, O, H, kitten, config1, compaction):
     c.close()
 
 
+def test_task_group_command_form(mc, O, ctx, kitten, config1):
+    """MCULL_CMD_NV_TASK_GROUPS: the NV record at the reference's granularity, taskCount = ceil(visible_i / 32) task
+    workgroups of 32 (Engine.cpp:1475-1483), firstTask = the draw's offset in the list as in the per-meshlet form."""
+    g, t = config1["globals"], config1["transforms"]
+    n = len(t)
+    ref = O.cull_scene(O.View(g), t, kitten["meshlets"], tests=3)
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    for stride, offset in ((0, 0), (28, 20)):
+        r = ctx.cull(g, tests=3, cmd_form=mc.CMD_NV_TASK_GROUPS, cmd_stride=stride, cmd_offset=offset)
+        st = stride or 8
+        raw = ctx.download_commands(n, st).reshape(n, st)
+        cmds = raw[:, offset:offset + 8].copy().view(mc.CMD).reshape(-1)
+        assert np.array_equal(cmds["taskCount"], (ref.commands["taskCount"] + 31) // 32)
+        assert np.array_equal(cmds["firstTask"], ref.commands["firstTask"])
+        assert ctx.download_list().tobytes() == ref.list.tobytes() and int(r.n_pairs) == ref.n_pairs
+        # a pass-through task stage: workgroup w of draw i forwards list[firstTask + 32 w + lane], 32 w + lane < visible_i
+        first = np.append(cmds["firstTask"].astype(np.int64), ref.total)
+        covered = sum(min(32, int(first[i + 1] - first[i]) - 32 * w) for i in range(n) for w in range(int(cmds["taskCount"][i])))
+        assert covered == ref.total
+    with pytest.raises(mc.McullError) as e:
+        ctx.cull(g, tests=3, cmd_form=3)
+    assert e.value.status == mc.E_INVALID
+
+
+def test_unknown_flag_bits_are_refused(mc, ctx, kitten, config1):
+    import ctypes
+
+    g, t = config1["globals"], config1["transforms"]
+    ctx.set_instance_ranges(None, None)
+    ctx.upload_meshlets(kitten["meshlets"])
+    ctx.upload_transforms(t)
+    gg = np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1)
+    for flags, want in ((8, mc.E_INVALID), (0x80000000, mc.E_INVALID), (7, mc.OK), (0, mc.OK)):
+        p = mc.CullParams(3, mc.COMPACT_ORDERED, 0, mc.CMD_NV_MESHLETS, 0, 0, 0, flags, None, 0, None, None)
+        r = mc.CullResult()
+        assert mc.lib.mcull_cull(ctx._h, gg.ctypes.data_as(ctypes.c_void_p), ctypes.byref(p), ctypes.byref(r)) == want
+    assert mc.version() >= 110
+
+
 def test_ext_command_form(mc, O, ctx, kitten, config1):
     """MCULL_CMD_EXT_GROUPS: {groupCountX = visible_i, 1, 1} records (12 bytes, or embedded at a
     caller-chosen stride/offset) plus the per-instance list offsets the EXT record has no room for."""

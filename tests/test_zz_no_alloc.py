@@ -3,8 +3,10 @@
 Called through the C ABI twice in a row on one GPU, the second time with a smaller scene, so that what the
 first call left in the GPU's static scratch array (ballots, tile counters, per-instance offsets) must not
 leak into the second.  Bar: list, commands, count and mask byte-identical to mcull_cull's (which the other
-GPU tests hold against the oracle).  Collected last (file name) and self-contained (own context), so it
-passes alone in a fresh process as well as after the other tests.
+GPU tests hold against the oracle).  The property the entry point exists for - no allocation - is checked by
+calling it under stream capture, where an allocation invalidates the capture, and replaying the graph.
+Collected last (file name) and self-contained (own contexts), so it passes alone in a fresh process as well
+as after the other tests.
 """
 import ctypes as C
 
@@ -12,6 +14,14 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def hip_runtime():
+    """The HIP runtime this process has already loaded (torch's), found through the process's own mappings."""
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return C.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime loaded")
 
 
 def run_both(mc, ctx, torch, g, n_inst, n_pairs, n_groups, tests, stride=8, offset=0):
@@ -35,7 +45,7 @@ def run_both(mc, ctx, torch, g, n_inst, n_pairs, n_groups, tests, stride=8, offs
             mask = np.zeros(n_groups, dtype="<u8")
             if n_groups:
                 assert r.mask, "a cull with groups reports where its ballots are"
-                hip = C.CDLL("libamdhip64.so.7")
+                hip = hip_runtime()
                 assert hip.hipMemcpy(mask.ctypes.data_as(C.c_void_p), C.c_void_p(r.mask), C.c_size_t(mask.nbytes), 2) == 0
         n = int(total.item())
         out[name] = (n, lst[:n].cpu().numpy().tobytes(), cmds.cpu().numpy().tobytes(), mask.tobytes())
@@ -101,3 +111,85 @@ def test_static_cull_rejects_what_does_not_fit(mc, H):
         with pytest.raises(mc.McullError) as e:
             ctx.cull_static(g1, buf.data_ptr(), 16, buf.data_ptr(), buf.data_ptr(), tests=1)
         assert e.value.status == mc.E_CAPACITY
+
+
+def test_static_cull_is_capturable_and_the_replayed_graph_equals_cull(mc, H):
+    """An allocation (hipMalloc / hipFree, torch's allocator) inside a stream capture invalidates the capture, so a
+    call that captures cleanly allocated nothing; the replayed graph must write what mcull_cull writes."""
+    torch = pytest.importorskip("torch")
+    stream = torch.cuda.Stream(device="cuda:0")
+    with mc.Context(0, stream=stream.cuda_stream) as ctx:
+        n_inst, per = 2000, 96
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=31)
+        t = H.synthetic_transforms(n_inst, extent=40.0, seed=32)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        g = H.create_globals(eye=(120.0, 110.0, 100.0), fov_deg=50.0, width=640, height=360, flip_y=False)
+        ctx.upload_bounds_soa(cone, sphere)
+        ctx.upload_transforms(t)
+        ctx.set_instance_ranges(off, cnt)
+        n_pairs = n_inst * per
+        tests = mc.TEST_FRUSTUM | mc.TEST_CONE
+        dev = "cuda:0"
+        bufs = {}
+        for name in ("ref", "graph"):
+            bufs[name] = (torch.full((n_pairs, 2), -1, dtype=torch.int32, device=dev), torch.zeros((n_inst, 2), dtype=torch.int32, device=dev),
+                          torch.full((1,), -1, dtype=torch.int64, device=dev))
+        lst, cmds, total = bufs["ref"]
+        ctx.cull(g, tests=tests, list_ptr=lst.data_ptr(), list_capacity=n_pairs, commands_ptr=cmds.data_ptr(), total_ptr=total.data_ptr())
+        ctx.synchronize()
+        lst, cmds, total = bufs["graph"]
+        ptrs = (lst.data_ptr(), cmds.data_ptr(), total.data_ptr())
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=stream):  # global capture mode: an allocating call would raise / invalidate
+            ctx.cull_static(g, ptrs[0], n_pairs, ptrs[1], ptrs[2], tests=tests)
+        assert int(total.item()) == -1, "capture records the launches, it does not run them"
+        for _ in range(2):
+            total.fill_(-1)
+            graph.replay()
+            torch.cuda.synchronize()
+            n = int(total.item())
+            assert n == int(bufs["ref"][2].item()) and 0 < n < n_pairs
+            assert torch.equal(lst[:n], bufs["ref"][0][:n]) and torch.equal(cmds, bufs["ref"][1])
+
+
+def test_static_cull_refuses_overlapping_use_and_unsupported_options(mc, H):
+    torch = pytest.importorskip("torch")
+    s1, s2 = torch.cuda.Stream(device="cuda:0"), torch.cuda.Stream(device="cuda:0")
+    with mc.Context(0, stream=s1.cuda_stream) as a, mc.Context(0, stream=s2.cuda_stream) as b:
+        n_inst, per = 8000, 128  # a millisecond or so of kernels: still running when the second call arrives
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=41)
+        t = H.synthetic_transforms(n_inst, extent=40.0, seed=42)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        g = H.create_globals(eye=(120.0, 110.0, 100.0), fov_deg=50.0, width=640, height=360, flip_y=False)
+        outs = []
+        for ctx in (a, b):
+            ctx.upload_bounds_soa(cone, sphere)
+            ctx.upload_transforms(t)
+            ctx.set_instance_ranges(off, cnt)
+            ctx.synchronize()
+            outs.append((torch.empty((n_inst * per, 2), dtype=torch.int32, device="cuda:0"), torch.zeros((n_inst, 2), dtype=torch.int32, device="cuda:0"),
+                         torch.zeros((1,), dtype=torch.int64, device="cuda:0")))
+        torch.cuda.synchronize()
+        args = [(o[0].data_ptr(), n_inst * per, o[1].data_ptr(), o[2].data_ptr()) for o in outs]
+        # a long-running kernel on stream 1 in front of the cull keeps the first call's event pending for certain
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(50_000_000)
+        a.cull_static(g, *args[0], tests=3)
+        with pytest.raises(mc.McullError) as e:
+            b.cull_static(g, *args[1], tests=3)
+        assert e.value.status == mc.E_STATE and "in use" in str(e.value)
+        a.cull_static(g, *args[0], tests=3)  # the same stream is ordered behind itself: allowed
+        torch.cuda.synchronize()
+        b.cull_static(g, *args[1], tests=3)  # the first user has finished
+        b.synchronize()
+        assert int(outs[1][2].item()) == int(outs[0][2].item()) > 0
+        # options the entry point does not honour are refused, not ignored
+        p = mc.CullParams(3, mc.COMPACT_ORDERED, 0, mc.CMD_NV_MESHLETS, 0, 0, 1, 0, *args[1])
+        r = mc.CullResult()
+        gg = np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1)
+        assert mc.lib.mcull_cull_static(b._h, gg.ctypes.data_as(C.c_void_p), C.byref(p), C.byref(r)) == mc.E_INVALID
+        p = mc.CullParams(3, mc.COMPACT_ORDERED, 0, mc.CMD_NV_MESHLETS, 0, 0, 0, 4, *args[1])
+        assert mc.lib.mcull_cull_static(b._h, gg.ctypes.data_as(C.c_void_p), C.byref(p), C.byref(r)) == mc.E_INVALID

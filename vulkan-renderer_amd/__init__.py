@@ -45,7 +45,7 @@ OK, E_INVALID, E_HIP, E_CAPACITY, E_STATE, E_NOMEM, E_IO = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 TEST_FRUSTUM, TEST_CONE, TEST_HIZ, TEST_ALL = 1, 2, 4, 7
 COMPACT_ORDERED, COMPACT_WAVE_ATOMIC, COMPACT_BLOCK_ATOMIC = 0, 1, 2
-CMD_NV_MESHLETS, CMD_EXT_GROUPS = 0, 1
+CMD_NV_MESHLETS, CMD_EXT_GROUPS, CMD_NV_TASK_GROUPS = 0, 1, 2
 CULL_NO_INSTANCE_PRECULL, CULL_EXACT_ARITHMETIC, CULL_COUNT_SLOW_PAIRS = 1, 2, 4
 CMD_EXT = np.dtype([("groupCountX", "<u4"), ("groupCountY", "<u4"), ("groupCountZ", "<u4")])
 MAX_HIZ_LEVELS, MAX_VIEWS = 16, 8

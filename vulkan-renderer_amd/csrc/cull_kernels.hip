@@ -1958,7 +1958,8 @@ __device__ __forceinline__ void emit_commands_body(
         first_task = my_first + (uint32_t)base;
     }
     uint32_t *out = (uint32_t *)(commands + (size_t)i * stride + offset);
-    out[0] = task_count;
+    // NV_TASK_GROUPS: task workgroups of 32 (the reference's granularity, Engine.cpp:1475-1483, shader.task:12)
+    out[0] = form == MCULL_CMD_NV_TASK_GROUPS ? (task_count + 31u) / 32u : task_count;
     if (form == MCULL_CMD_EXT_GROUPS) {  // {groupCountX, groupCountY, groupCountZ}
         out[1] = 1u;
         out[2] = 1u;
@@ -2452,6 +2453,27 @@ hipError_t launch_rebase_gathered(void *gathered, uint32_t world, uint64_t rows,
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(rebase_gathered_kernel, dim3((uint32_t)bx, world), dim3(kBlock), 0, st, (uint2 *)gathered, world, rows,
                        (unsigned long long *)totals, (unsigned long long *)bases);
+    return hipGetLastError();
+}
+
+// n words of zero, as a kernel: a memset node in a captured graph was seen to leave garbage from the second replay
+// on (ROCm 7.2), and this is what callers under stream capture reach for.
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t *__restrict__ p, uint64_t n) {
+    // 16-byte stores over the aligned middle, single words at the ragged ends
+    const uint64_t head = (4u - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3u)) & 3u;
+    const uint64_t h = head < n ? head : n, quads = (n - h) / 4, tail = h + quads * 4;
+    uint4 *q = reinterpret_cast<uint4 *>(p + h);
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < quads; i += (uint64_t)gridDim.x * kBlock) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) p[threadIdx.x] = 0u;
+        if (tail + threadIdx.x < n) p[tail + threadIdx.x] = 0u;
+    }
+}
+
+hipError_t launch_zero_words(uint32_t *p, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n / 4 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((uint32_t)(blocks < 1 ? 1 : blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, st, p, n);
     return hipGetLastError();
 }
 

@@ -55,7 +55,7 @@ __global__ void group_pack_kernel(const uint8_t *__restrict__ staged, GroupLayou
     const uint32_t words = lay.stride / 4, first_task_word = lay.offset / 4 + 1;
     for (uint32_t w = 0; w < words; w++) {
         uint32_t x = src[w];
-        if (lay.form == MCULL_CMD_NV_MESHLETS && w == first_task_word) x += (uint32_t)base;
+        if (lay.form != MCULL_CMD_EXT_GROUPS && w == first_task_word) x += (uint32_t)base;
         dst[w] = x;
     }
     if (lay.form == MCULL_CMD_EXT_GROUPS)
@@ -281,7 +281,7 @@ int mcull_group_cull(mcull_group *g, const mcull_globals *globals, const mcull_c
     if (p.compaction != MCULL_COMPACT_ORDERED)
         return gfail(g, MCULL_E_INVALID, "a group culls with ordered compaction only (firstTask must be a scan to be rebased)");
     if (p.list || p.commands || p.total) return gfail(g, MCULL_E_INVALID, "a group owns its output buffers: list, commands and total must be null");
-    if (p.cmd_form > MCULL_CMD_EXT_GROUPS) return gfail(g, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
+    if (p.cmd_form > MCULL_CMD_NV_TASK_GROUPS) return gfail(g, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
     const uint32_t record = p.cmd_form == MCULL_CMD_EXT_GROUPS ? 12u : 8u;
     if (p.cmd_stride == 0) p.cmd_stride = record;
     if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + record > p.cmd_stride)

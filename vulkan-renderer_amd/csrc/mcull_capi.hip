@@ -13,7 +13,7 @@
 
 #include "mcull_internal.h"
 
-#define MCULL_VERSION_NUMBER 100
+#define MCULL_VERSION_NUMBER 110  // 110: mcull_scene_load(expected), mcull_cull_params.flags, MCULL_CMD_NV_TASK_GROUPS
 
 namespace {
 
@@ -61,6 +61,15 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_lock;
 unsigned char *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each device, once resolved
+// Who used a device's array last: an event recorded behind that call's launches (created with the address, in
+// mcull_create, so that mcull_cull_static itself creates nothing) and the stream it was recorded on.
+struct ScratchGuard {
+    std::mutex lock;
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr;
+    bool recorded = false;
+};
+ScratchGuard g_scratch_guard[kMaxDevices];
 
 // Device address of this device's copy of `scratch`; the device must be current.
 hipError_t scratch_address(int device, unsigned char **out) {
@@ -73,6 +82,7 @@ hipError_t scratch_address(int device, unsigned char **out) {
         if (e != hipSuccess) return e;
         if (!ptr) return hipErrorInvalidSymbol;
         g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+        if (!g_scratch_guard[device].done) (void)hipEventCreateWithFlags(&g_scratch_guard[device].done, hipEventDisableTiming);
     }
     *out = g_scratch_ptr[device];
     return hipSuccess;
@@ -225,7 +235,15 @@ void release(DevBuf &b) {
 
 // a changed scene makes every stored cull result meaningless
 void invalidate_results(mcull_ctx *c) {
-    for (auto &o : c->out) o.last.valid = false;
+    for (auto &o : c->out) {
+        o.last.valid = false;
+        // what the pre-cull learnt about the old scene says nothing about the new one
+        o.probe_pending = false;
+        o.list_estimate = 0;
+        o.precull_cooldown = o.group_cooldown = 0;
+    }
+    c->views_probe_pending = false;
+    c->views_cooldown = 0;
     c->cur = 0;
 }
 
@@ -741,6 +759,7 @@ struct CullPlan {
     bool hand_on;               // the list's entries carry what the instance level has settled (cull_mask_kernel<..., FLAGS>)
     uint32_t *group_work;       // list of the group level behind it, nullptr when that does not run
     uint64_t list_estimate;     // groups the work list is expected to hold (0 = unknown), see launch_cull_mask
+    bool reports;               // this cull's passes leave their counts in host-mapped memory (it armed the slot's probe)
 };
 
 // The half of the plan that allocates nothing: validated parameters, scene and view constants, sizes.
@@ -756,7 +775,9 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     if (p.cmd_stride == 0) p.cmd_stride = record;
     if (p.tests & ~MCULL_TEST_ALL) return fail(c, MCULL_E_INVALID, "unknown test bits 0x%x", p.tests);
     if (p.compaction > MCULL_COMPACT_BLOCK_ATOMIC) return fail(c, MCULL_E_INVALID, "unknown compaction %u", p.compaction);
-    if (p.cmd_form > MCULL_CMD_EXT_GROUPS) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
+    if (p.cmd_form > MCULL_CMD_NV_TASK_GROUPS) return fail(c, MCULL_E_INVALID, "unknown command form %u", p.cmd_form);
+    if (p.flags & ~(uint32_t)(MCULL_CULL_NO_INSTANCE_PRECULL | MCULL_CULL_EXACT_ARITHMETIC | MCULL_CULL_COUNT_SLOW_PAIRS))
+        return fail(c, MCULL_E_INVALID, "unknown flag bits 0x%x", p.flags);
     if ((p.cmd_stride & 3u) || (p.cmd_offset & 3u) || p.cmd_offset + record > p.cmd_stride)
         return fail(c, MCULL_E_INVALID, "command stride/offset must be 4-byte multiples with offset+%u <= stride", record);
     if ((p.tests & MCULL_TEST_HIZ) && (p.hiz_view >= MCULL_MAX_VIEWS || !c->hiz[p.hiz_view].built))
@@ -818,6 +839,7 @@ int plan_inputs(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, co
     plan->work = nullptr;
     plan->precull_units = 0;
     plan->hand_on = false;
+    plan->reports = false;
     plan->group_work = nullptr;
     plan->list_estimate = 0;
     plan->n_tiles = mcull::tile_count_for(s.n_groups);
@@ -858,7 +880,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     o.counts_slow_pairs = (p.flags & MCULL_CULL_COUNT_SLOW_PAIRS) != 0;
     if (o.counts_slow_pairs) {  // a spare word of the context-owned count buffer, zero at the start of the cull
         plan->v.slow_pairs = (unsigned long long *)o.total.p + 16;
-        HIPCHK(c, hipMemsetAsync(plan->v.slow_pairs, 0, 8, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)plan->v.slow_pairs, 2, c->stream));
     }
     plan->list = p.list;
     plan->capacity = p.list_capacity;
@@ -875,7 +897,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
         const uint64_t layout_key = ((uint64_t)p.cmd_stride << 32) | ((uint64_t)p.cmd_form << 24) | p.cmd_offset;
         const bool fresh = !o.commands.p || o.commands.cap < bytes || o.commands_layout != layout_key;
         if ((rc = ensure(c, o.commands, bytes))) return rc;
-        if (fresh) HIPCHK(c, hipMemsetAsync(o.commands.p, 0, o.commands.cap, c->stream));
+        if (fresh) HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.commands.p, o.commands.cap / 4, c->stream));
         o.commands_layout = layout_key;
         plan->commands = o.commands.p;
     }
@@ -932,6 +954,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
                 if (plan->group_work) c->kept_host[2] = 0xffffffffu;       // and its group level (single-view culls are slot 0)
                 o.probe_pending = true;
+                plan->reports = true;  // only this cull writes the words: an earlier one still in flight cannot overwrite the sentinel
                 o.probe_units = plan->group_work ? s.n_groups : plan->precull_units;
                 o.probe_group_level = plan->group_work != nullptr;
                 o.probe_in_groups = ranged;
@@ -949,7 +972,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
         if ((rc = ensure(c, o.tile_counts, (size_t)plan->n_tiles * 4))) return rc;
         if (plan->two_level && (rc = ensure(c, o.tile_offsets, (size_t)plan->n_tiles * 8))) return rc;
         if ((rc = ensure(c, o.inst_first, (c->n_instances + 1) * 4))) return rc;
-        if (!o.counters_clean) HIPCHK(c, hipMemsetAsync(o.tile_counts.p, 0, o.tile_counts.cap, c->stream));
+        if (!o.counters_clean) HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.tile_counts.p, o.tile_counts.cap / 4, c->stream));
         o.counters_clean = false;  // until the command kernel that re-zeroes them has been enqueued
     }
     return MCULL_OK;
@@ -1021,34 +1044,34 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         HIPCHK(c, hipGetLastError());
     }
     if (pl.s.n_groups == 0) {
-        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)pl.total, 2, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.inst_count.p, c->n_instances + 1, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
                                               (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands, nullptr, c->stream));
     } else if (pl.p.compaction == MCULL_COMPACT_ORDERED) {
         const bool hand_on = pl.work && pl.hand_on;
         if (pl.work) {
             // the mask pass will cover the work list's groups only: every other ballot is zero from here
-            HIPCHK(c, hipMemsetAsync(pl.work, 0, 4, c->stream));
+            HIPCHK(c, mcull::launch_zero_words(pl.work, 1, c->stream));
             // few groups per instance: the pre-pass zeroes the dropped groups' ballots itself; many: one memset
             const bool inline_zero = pl.s.n_groups <= 8ull * pl.s.n_instances;
-            if (!inline_zero) HIPCHK(c, hipMemsetAsync(o.mask.p, 0, pl.s.n_groups * 8, c->stream));
+            if (!inline_zero) HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.mask.p, pl.s.n_groups * 2, c->stream));
             HIPCHK(c, mcull::launch_instance_precull(pl.s, (const float4 *)c->range_spheres.p, c->have_ranges,
                                                      c->have_ranges ? (const uint32_t *)c->group_base.p : nullptr, pl.v, view_dev,
                                                      pl.work, inline_zero ? (uint64_t *)o.mask.p : nullptr, hand_on, c->stream,
                                                      pl.group_work));
             if (pl.group_work)
                 HIPCHK(c, mcull::launch_group_precull(pl.s, (const float4 *)c->group_spheres.p, (uint32_t)c->n_meshlets, pl.v, view_dev,
-                                                      pl.work, pl.group_work, c->stream, c->precull_adaptive ? c->kept_dev + 2 : nullptr));
+                                                      pl.work, pl.group_work, c->stream, pl.reports ? c->kept_dev + 2 : nullptr));
         }
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, (uint64_t *)o.mask.p, (uint32_t *)o.tile_counts.p, pl.streaming,
                                           c->stream, view_dev, pl.group_work ? pl.group_work : pl.work,
-                                          c->precull_adaptive ? c->kept_dev : nullptr, hand_on, pl.group_work != nullptr,
+                                          pl.reports ? c->kept_dev : nullptr, hand_on, pl.group_work != nullptr,
                                           pl.work && !hand_on ? pl.list_estimate : 0));
         if (int rc = launch_ordered_tail(c, o, pl)) return rc;
     } else {
-        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)pl.total, 2, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.inst_count.p, c->n_instances + 1, c->stream));
         HIPCHK(c, mcull::launch_cull_atomic(pl.s, pl.v, pl.list, pl.capacity, (uint32_t *)o.inst_count.p, pl.total,
                                             pl.p.write_mask ? (uint64_t *)o.mask.p : nullptr,
                                             pl.p.compaction == MCULL_COMPACT_BLOCK_ATOMIC, c->stream));
@@ -1085,6 +1108,8 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
         return fail(c, MCULL_E_INVALID, "mcull_cull_static needs caller-owned list, commands and total");
     if (params->compaction != MCULL_COMPACT_ORDERED)
         return fail(c, MCULL_E_INVALID, "mcull_cull_static supports ordered compaction only");
+    if (params->write_mask || (params->flags & MCULL_CULL_COUNT_SLOW_PAIRS))
+        return fail(c, MCULL_E_INVALID, "mcull_cull_static supports neither write_mask nor MCULL_CULL_COUNT_SLOW_PAIRS");
     HIPCHK(c, hipSetDevice(c->device));
     CullPlan pl;
     if (int rc = plan_inputs(c, g, 0, params, &pl)) return rc;
@@ -1096,6 +1121,14 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
                     (unsigned long long)c->n_instances, (unsigned long long)MCULL_STATIC_MAX_INSTANCES);
     unsigned char *ptr = c->static_scratch;  // resolved by mcull_create with this device current
     if (!ptr) return fail(c, MCULL_E_STATE, "the static scratch of device %d was never resolved", c->device);
+    // One user of the array at a time: refuse when the last call on this GPU came from another stream and has not finished.
+    ScratchGuard &guard = g_scratch_guard[c->device];
+    std::lock_guard<std::mutex> hold(guard.lock);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    HIPCHK(c, hipStreamIsCapturing(c->stream, &capturing));
+    if (capturing == hipStreamCaptureStatusNone && guard.recorded && guard.stream != c->stream && guard.done &&
+        hipEventQuery(guard.done) == hipErrorNotReady)
+        return fail(c, MCULL_E_STATE, "the static scratch of device %d is in use by a cull on another stream", c->device);
     uint64_t *mask = reinterpret_cast<uint64_t *>(ptr + kStaticMaskOff);
     uint32_t *tile_counts = reinterpret_cast<uint32_t *>(ptr + kStaticTileOff);
     uint64_t *tile_offsets = reinterpret_cast<uint64_t *>(ptr + kStaticOffsetsOff);
@@ -1106,20 +1139,25 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
     pl.commands = params->commands;
     if (pl.s.n_groups == 0) {
         // no pair at all: zero commands from zero per-instance counts (kept in the inst_first region)
-        HIPCHK(c, hipMemsetAsync(pl.total, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(inst_first, 0, (c->n_instances + 1) * 4, c->stream));
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)pl.total, 2, c->stream));
+        HIPCHK(c, mcull::launch_zero_words(inst_first, c->n_instances + 1, c->stream));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, nullptr, inst_first, (const uint64_t *)pl.total, nullptr,
                                               0, pl.lay, pl.commands, nullptr, c->stream));
     } else {
         // the array keeps the previous call's contents (any context of this GPU may have made it): the
         // counters the mask pass adds into start at zero
-        HIPCHK(c, hipMemsetAsync(tile_counts, 0, (size_t)pl.n_tiles * 4, c->stream));
+        HIPCHK(c, mcull::launch_zero_words(tile_counts, pl.n_tiles, c->stream));
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, mask, tile_counts, pl.streaming, c->stream, nullptr));
         HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? tile_offsets : nullptr, pl.list, pl.capacity,
                                         inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, inst_first, nullptr, (const uint64_t *)pl.total, nullptr, 0,
                                               pl.lay, pl.commands, tile_counts, c->stream, pl.two_level ? tile_offsets : nullptr,
                                               inst_first));
+    }
+    if (capturing == hipStreamCaptureStatusNone && guard.done) {
+        HIPCHK(c, hipEventRecord(guard.done, c->stream));
+        guard.recorded = true;
+        guard.stream = c->stream;
     }
     if (result) {
         result->list = pl.list;
@@ -1169,8 +1207,8 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
     if (pl[0].s.n_groups == 0) {
         for (uint32_t i = 0; i < n_views; i++) {
             mcull_ctx::ViewOut &o = c->out[i];
-            HIPCHK(c, hipMemsetAsync(pl[i].total, 0, 8, c->stream));
-            HIPCHK(c, hipMemsetAsync(o.inst_count.p, 0, (c->n_instances + 1) * 4, c->stream));
+            HIPCHK(c, mcull::launch_zero_words((uint32_t *)pl[i].total, 2, c->stream));
+            HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.inst_count.p, c->n_instances + 1, c->stream));
             HIPCHK(c, mcull::launch_emit_commands(pl[i].s, pl[i].uniform_count, nullptr, (const uint32_t *)o.inst_count.p,
                                                   (const uint64_t *)pl[i].total, nullptr, 0, pl[i].lay, pl[i].commands, nullptr,
                                                   c->stream));
@@ -1212,7 +1250,7 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
             if (int rc = ensure_range_spheres(c, pl[0].s, pl[0].uniform_count)) return rc;
             if (int rc = ensure(c, c->view_flags, (size_t)c->n_instances * MCULL_MAX_VIEWS)) return rc;
             useful_dev = (uint32_t *)c->out[0].total.p + 48;  // a spare word of the context-owned count buffer
-            HIPCHK(c, hipMemsetAsync(useful_dev, 0, 4, c->stream));
+            HIPCHK(c, mcull::launch_zero_words(useful_dev, 1, c->stream));
             HIPCHK(c, mcull::launch_classify_views(pl[0].s, (const float4 *)c->range_spheres.p, c->have_ranges, n_views, vc, view_dev,
                                                    (uint8_t *)c->view_flags.p, useful_dev, c->stream));
             if (c->precull_adaptive && !c->views_probe_pending) {
@@ -1277,6 +1315,7 @@ int mcull_rebase_commands(mcull_ctx *c, const uint64_t *device_totals, uint32_t 
     if (!device_totals && rank) return fail(c, MCULL_E_INVALID, "device_totals is null");
     if (o.last.lay.form == MCULL_CMD_EXT_GROUPS)
         return fail(c, MCULL_E_INVALID, "EXT records carry no firstTask to rebase; offset first_task on the consumer side");
+    // (NV_TASK_GROUPS records carry the same firstTask as NV_MESHLETS records and are rewritten the same way)
     HIPCHK(c, hipSetDevice(c->device));
     const bool ordered = o.last.compaction == MCULL_COMPACT_ORDERED && o.last.scene.n_groups > 0;
     HIPCHK(c, mcull::launch_emit_commands(o.last.scene, o.last.uniform_count,
@@ -1460,7 +1499,7 @@ int raster_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev
     }
     if (!c->raster_scratch.p) {
         if (int rc = ensure(c, c->raster_scratch, mcull::depth_raster_scratch_bytes())) return rc;
-        HIPCHK(c, hipMemsetAsync(c->raster_scratch.p, 0, 256, c->stream));  // the queue counters; the kernels keep them zero between calls
+        HIPCHK(c, mcull::launch_zero_words((uint32_t *)c->raster_scratch.p, 64, c->stream));  // the queue counters; the kernels keep them zero between calls
     }
     if (int rc = ensure(c, c->raster_mvp, (size_t)(c->n_instances ? c->n_instances : 1) * 64)) return rc;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));

@@ -157,6 +157,7 @@ hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const
 hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visible *list, uint64_t capacity,
                               uint32_t *inst_count, uint64_t *total, uint64_t *mask, bool block_mode, hipStream_t st);
 hipError_t launch_rebase_gathered(void *gathered, uint32_t world, uint64_t rows, uint64_t *totals, uint64_t *bases, hipStream_t st);
+hipError_t launch_zero_words(uint32_t *p, uint64_t n_words, hipStream_t st);  // a kernel, not a memset node (see there)
 hipError_t launch_xform_scale(const float4 *transforms, uint32_t n, float *xf_scale, hipStream_t st);
 hipError_t launch_fill_group_rec(const uint2 *ranges, const uint32_t *group_base, uint32_t n_instances,
                                  uint4 *group_rec, hipStream_t st);

@@ -106,8 +106,9 @@ def rebase_gathered(gathered, world, rows, out=None):
             _package = importlib.import_module(__package__)
         if out is None:
             out = torch.empty((2, world), dtype=torch.int64, device=gathered.device)
-        _package.rebase_gathered_commands(torch.cuda.current_stream(gathered.device).cuda_stream, gathered.data_ptr(), world, rows - 1,
-                                          out[0].data_ptr(), out[1].data_ptr())
+        with torch.cuda.device(gathered.device):  # the library launches on the current device: make it the tensor's
+            _package.rebase_gathered_commands(torch.cuda.current_stream(gathered.device).cuda_stream, gathered.data_ptr(), world, rows - 1,
+                                              out[0].data_ptr(), out[1].data_ptr())
         return out[0], g[:, : rows - 1, :]
     return rebase_gathered_tensor_ops(gathered, world, rows)
 
