@@ -1,10 +1,10 @@
 """The Hi-Z kernel that finishes the pyramid inside one launch hands texels from one workgroup to another
-through memory: a producer stores its level-6 (and later level-9) texel write-through, drains the store
-(`s_waitcnt vmcnt(0)`) and only then takes its ticket with a returning atomic; a consumer reads the texels with
-agent-scope loads after its own ticket has returned.  That order is what makes the hand-over correct without
-any cache-wide flush, and it rests on the instructions the compiler emits.  This test compiles the kernels
-for gfx950 and pins them: scope bits on the hand-over stores and loads, the drain directly in front of every
-ticket.  No GPU needed (hipcc cross-compiles)."""
+through memory: a producer stores its level-6 (and later level-9) texel and takes a ticket with a RELEASE at agent
+scope; the workgroup whose ticket is the last of its counter executes an ACQUIRE fence and reads the texels.
+That is the memory model's own pattern, so nothing rests on hand-placed instructions any more; this test compiles the
+kernels for gfx950 and checks that the pattern is what the compiler emitted - a cache write-back and a drained
+store queue in front of every ticket, a cache invalidate behind it on the last arriver's path and in front of its
+first hand-over load - and that no inline assembly is left in the file.  No GPU needed (hipcc cross-compiles)."""
 import os
 import re
 import subprocess
@@ -54,29 +54,32 @@ def test_every_instantiation_is_there(kernels):
     assert len(tiles) == 8 and sum(single_pass(k) for k in tiles) == 4
 
 
-def test_handover_stores_loads_and_tickets(kernels):
+def test_handover_is_release_on_the_ticket_and_acquire_by_the_last_arriver(kernels):
     for name, body in kernels.items():
-        stores = [t for t in body if t.startswith("global_store") and "sc1" in t.split()]
-        loads = [t for t in body if t.startswith("global_load") and "sc1" in t.split()]
+        assert not [t for t in body if "#ASM" in t], (name, "inline assembly")
         atomics = [i for i, t in enumerate(body) if t.startswith("global_atomic")]
         if not single_pass(name):
-            assert not stores and not loads and not atomics, name
+            assert not atomics, name
             continue
-        # level 6 and level 9: one dword each, written through to memory (agent scope)
-        assert len(stores) == 2 and all(t.startswith("global_store_dword ") for t in stores), (name, stores)
-        # the consumers' reads: one level-6 texel per lane, then four level-9 texels per lane
-        assert len(loads) == 5 and all(t.startswith("global_load_dword ") for t in loads), (name, loads)
-        # two tiers of tickets, each a returning (sc0) add ...
+        # two tiers of tickets, each a returning (sc0) add
         assert len(atomics) == 2, (name, [body[i] for i in atomics])
-        for i in atomics:
+        for n, i in enumerate(atomics):
             assert body[i].startswith("global_atomic_add ") and "sc0" in body[i].split(), (name, body[i])
-            # ... with the hand-written drain in front of it and no memory instruction in between
-            back = body[max(0, i - 40):i]
-            ends = [j for j, t in enumerate(back) if "#ASMEND" in t]
-            assert ends, (name, "no inline asm in front of the ticket")
-            j = ends[-1]
-            assert back[j - 1] == "s_waitcnt vmcnt(0)" and "#ASMSTART" in back[j - 2], (name, back[j - 2:j + 1])
-            assert not [t for t in back[j + 1:] if is_mem(t)], (name, back[j + 1:])
-        # a consumer's first hand-over load comes after a ticket in program text, never before the first one
-        first_load = min(i for i, t in enumerate(body) if t.startswith("global_load") and "sc1" in t.split())
-        assert first_load > atomics[0], name
+            # release at agent scope: this XCD's L2 written back and every earlier store of the wave drained
+            back = body[max(0, i - 12):i]
+            wb = [j for j, t in enumerate(back) if t.startswith("buffer_wbl2") and "sc1" in t.split()]
+            assert wb, (name, "no L2 write-back in front of the ticket", back)
+            waits = [t for t in back[wb[-1] + 1:] if t.startswith("s_waitcnt") and "vmcnt(0)" in t]
+            assert waits, (name, "stores not drained between the write-back and the ticket", back)
+            assert not [t for t in back[wb[-1] + 1:] if t.startswith(("global_store", "buffer_store", "flat_store"))], (name, back)
+            # acquire by the last arriver: an invalidate between this ticket and the first hand-over load behind it
+            end = atomics[n + 1] if n + 1 < len(atomics) else len(body)
+            after = body[i + 1:end]
+            inv = [j for j, t in enumerate(after) if t.startswith("buffer_inv") and "sc1" in t.split()]
+            loads = [j for j, t in enumerate(after) if t.startswith("global_load") and "sc1" in t.split()]
+            assert inv, (name, "no invalidate behind ticket %d" % n)
+            if loads:
+                assert inv[0] < loads[0], (name, "a hand-over load in front of the acquire")
+        # the consumers' reads are agent-scope loads: one level-6 texel per lane, then four level-9 texels per lane
+        loads = [t for t in body[atomics[0]:] if t.startswith("global_load") and "sc1" in t.split()]
+        assert len(loads) == 5 and all(t.startswith("global_load_dword ") for t in loads), (name, loads)

@@ -83,11 +83,8 @@ __global__ __launch_bounds__(kBlock) void hiz_generic_kernel(const float *__rest
     }
 }
 
-// Texels handed from one workgroup to another inside a launch are stored write-through and read
-// back with agent-scope loads, which are served coherently across the XCDs' L2s.  That keeps the
-// hand-off free of cache-wide operations: an acquire fence would invalidate the reader's whole L2
-// once per ticket group, and those invalidations pile up at the end of a launch that fits the
-// machine in one round (measured +8 us at 3840x2160).
+// Texels handed from one workgroup to another inside a launch are stored and read back with agent-scope
+// atomic accesses (no data race on them in the memory model's sense); what orders them is the ticket.
 __device__ __forceinline__ float coherent_load(const float *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -258,26 +255,27 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
 
     // ---- levels 7..: handed to whichever workgroup finishes last, by wave 0 alone (waves 1-3 are done
     // and leave; nothing below uses a workgroup barrier or LDS).  Each workgroup produced exactly one
-    // level-6 texel, written by thread 0 with a write-through (agent-scope) store; wave 0 drains that
-    // store and takes a ticket in the counter of its 8x8 block of tiles.  The last arriver of a block
-    // owns that block's 8x8 level-6 texels = one texel per lane, reduces levels 7-9 with lane
-    // shuffles, and takes a ticket in the top counter; the last arriver there reduces the (at most
-    // 16x16) level-9 texels to the apex.  A consumer's loads are issued only after its ticket has
-    // returned, and every producer's texel had reached memory before its ticket was taken, so no
-    // L2 write-back or invalidate is needed on either side, and no
-    // word receives more than 256 tickets (a single word sustains only ~90 returning atomics per
-    // microsecond, which 16 384 workgroups would queue on).
+    // level-6 texel, written by thread 0, which then takes a ticket in the counter of its 8x8 block of
+    // tiles with a RELEASE at agent scope.  The last arriver of a block - and only it - executes an
+    // ACQUIRE fence, owns that block's 8x8 level-6 texels = one texel per lane, reduces levels 7-9 with
+    // lane shuffles, and takes a ticket in the top counter the same way; the last arriver there
+    // reduces the (at most 16x16) level-9 texels to the apex.  Release on every ticket of a counter and
+    // acquire by the one that reads the final value is the memory model's own pattern for "the last one
+    // in sees everybody's writes" (the read-modify-writes of a counter form one release sequence), so the
+    // hand-over does not rest on instruction order.  Measured against an earlier form that did (write-
+    // through stores drained with a hand-placed s_waitcnt, relaxed tickets, no fences): + 0.5 us at
+    // 3840x2160, + 2.3 us (2 %) at 8192^2, nothing at 1920x1080; the acquire by EVERY workgroup, which
+    // invalidates an L2 each time, had cost 8 us.  No word receives more than 256 tickets (a single
+    // word sustains only ~90 returning atomics per microsecond, which 16 384 workgroups would queue on).
     const uint32_t gx = blockIdx.x >> 3, gy = blockIdx.y >> 3;
     const uint32_t groups_x = (gridDim.x + 7u) >> 3, groups_y = (gridDim.y + 7u) >> 3;
     uint32_t last = 0u;
     if (t == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t members = min(8u, gridDim.x - 8u * gx) * min(8u, gridDim.y - 8u * gy);
-        last = __hip_atomic_fetch_add(counter + 1u + gy * groups_x + gx, 1u, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT) == members - 1u;
+        last = __hip_atomic_fetch_add(counter + 1u + gy * groups_x + gx, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == members - 1u;
     }
     if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
         const uint32_t w6 = tbl[6], h6 = tbl[16 + 6];
         const uint32_t x = min(8u * gx + (t & 7u), w6 - 1u), y = min(8u * gy + (t >> 3), h6 - 1u);
@@ -288,15 +286,14 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     }
     last = 0u;
     if (t == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups_x * groups_y - 1u;
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == groups_x * groups_y - 1u;
     }
     if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
     // every ticket of this launch has been taken: leave the words zero for the next launch on the
     // stream (they are zeroed once at allocation; no per-call memset is needed)
     for (uint32_t i = t; i <= groups_x * groups_y; i += 64u) counter[i] = 0u;
     if (levels <= 10) return;
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
         // lane (x,y) of an 8x8 arrangement owns the 2x2 patch of level 9 at (2x,2y) -> one texel of level 10
         const uint32_t w9 = tbl[9], h9 = tbl[16 + 9];
