@@ -362,6 +362,27 @@ int mcull_rebase_commands(mcull_ctx *ctx, const uint64_t *device_totals, uint32_
 int mcull_rebase_gathered_commands(void *stream, void *gathered, uint32_t world, uint64_t rows_per_rank, uint64_t *totals,
                                    uint64_t *bases);
 
+/* The same step with the collective inside: all-gathers this rank's block (rows_per_rank + 1 records, as above) from
+ * `send_block` into `gathered` (`world` blocks; device memory, the caller's) with RCCL's ncclAllGather on `stream`,
+ * then rebases the gathered firstTask values on that stream as mcull_rebase_gathered_commands does.  `comm` is an
+ * ncclComm_t the caller owns (one process per GPU; any way of creating it will do - mcull_rccl_comm_create below
+ * is one).  Asynchronous: two enqueues, no host synchronisation, capturable.  RCCL is looked up at run time, not
+ * linked: the copy the process already holds (PyTorch's) is reused, else the system's librccl.so.1 is loaded;
+ * MCULL_E_STATE when there is none (mcull_collective_last_error() says why, per thread).  No reference counterpart:
+ * the reference drives one device (Engine.cpp:658-666). */
+int mcull_allgather_commands(void *nccl_comm, void *stream, const void *send_block, void *gathered, uint32_t world,
+                             uint64_t rows_per_rank, uint64_t *totals, uint64_t *bases);
+
+/* Communicator plumbing for hosts that have no other RCCL binding: rank 0 calls mcull_rccl_unique_id, ships the
+ * MCULL_RCCL_UNIQUE_ID_BYTES bytes to the other ranks by whatever means it has (a file, a socket, a
+ * torch.distributed broadcast), and every rank calls mcull_rccl_comm_create (collective: returns when all `world`
+ * ranks have called it; makes device_ordinal current).  No reference counterpart. */
+#define MCULL_RCCL_UNIQUE_ID_BYTES 128
+int mcull_rccl_unique_id(void *id_128_bytes);
+int mcull_rccl_comm_create(const void *id_128_bytes, int world, int rank, int device_ordinal, void **nccl_comm);
+int mcull_rccl_comm_destroy(void *nccl_comm);
+const char *mcull_collective_last_error(void);
+
 /* The literal per-32 task payloads of shader.task:28-35,:103-118 for the last ordered
  * mcull_cull: one record per (instance, group of 32 meshlets).  `out` is a device buffer
  * of at least mcull_task_payload_count() records. */

@@ -68,7 +68,9 @@ ABI_SYMBOLS = [
     "mcull_cull_views_device_globals", "mcull_cull_static", "mcull_precull_stats", "mcull_precull_group_stats", "mcull_slow_path_pairs", "mcull_rebase_gathered_commands",
     "mcull_group_create", "mcull_group_destroy", "mcull_group_size", "mcull_group_ctx", "mcull_group_last_error",
     "mcull_group_cull", "mcull_group_synchronize", "mcull_group_download", "mcull_group_frame",
+    "mcull_allgather_commands", "mcull_rccl_unique_id", "mcull_rccl_comm_create", "mcull_rccl_comm_destroy", "mcull_collective_last_error",
 ]
+RCCL_UNIQUE_ID_BYTES = 128
 GROUP_MAX_SHARDS = 64
 
 
@@ -120,6 +122,11 @@ _sig("mcull_precull_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER
 _sig("mcull_precull_group_stats", _I, [_P, C.POINTER(_U64), C.POINTER(_U64)])
 _sig("mcull_rebase_commands", _I, [_P, _P, _U32])
 _sig("mcull_rebase_gathered_commands", _I, [_P, _P, _U32, _U64, _P, _P])
+_sig("mcull_allgather_commands", _I, [_P, _P, _P, _P, _U32, _U64, _P, _P])
+_sig("mcull_rccl_unique_id", _I, [_P])
+_sig("mcull_rccl_comm_create", _I, [_P, _I, _I, _I, C.POINTER(_P)])
+_sig("mcull_rccl_comm_destroy", _I, [_P])
+_sig("mcull_collective_last_error", C.c_char_p, [])
 _sig("mcull_task_payload_count", _U64, [_P])
 _sig("mcull_emit_task_payloads", _I, [_P, _P])
 _sig("mcull_download_count", _I, [_P, C.POINTER(_U64)])
@@ -187,6 +194,50 @@ class McullError(RuntimeError):
 
 def version():
     return int(lib.mcull_version())
+
+
+def _collective_chk(rc, what):
+    if rc != OK:
+        raise McullError(rc, "%s: %s" % (what, (lib.mcull_collective_last_error() or b"").decode()))
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes them, every rank of the communicator needs them)."""
+    buf = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
+    _collective_chk(lib.mcull_rccl_unique_id(buf), "mcull_rccl_unique_id")
+    return buf.raw
+
+
+class RcclComm:
+    """An ncclComm_t made by the library (mcull_rccl_comm_create: collective over `world` ranks)."""
+
+    def __init__(self, unique_id, world, rank, device):
+        self._h = _P()
+        _collective_chk(lib.mcull_rccl_comm_create(C.c_char_p(unique_id), world, rank, device, C.byref(self._h)), "mcull_rccl_comm_create")
+        self.world, self.rank = world, rank
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _collective_chk(lib.mcull_rccl_comm_destroy(self._h), "mcull_rccl_comm_destroy")
+            self._h = _P()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def allgather_commands(comm, stream, send_ptr, gathered_ptr, world, rows_per_rank, totals_ptr, bases_ptr):
+    """mcull_allgather_commands: ncclAllGather of this rank's command block + the rebase of the gathered firstTask
+    values, both enqueued on `stream` (a hipStream_t value) by the library; `comm` an RcclComm or a raw ncclComm_t."""
+    h = comm.handle if isinstance(comm, RcclComm) else comm
+    _collective_chk(lib.mcull_allgather_commands(h, stream, send_ptr, gathered_ptr, world, rows_per_rank, totals_ptr, bases_ptr),
+                    "mcull_allgather_commands")
 
 
 def rebase_gathered_commands(stream, gathered_ptr, world, rows_per_rank, totals_ptr, bases_ptr):

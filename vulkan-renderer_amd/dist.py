@@ -90,6 +90,15 @@ def gather_visible_lists(list_local, totals_all, out=None, group=None, first_ins
 _package = None  # the ctypes binding, imported on first use (this module is importable without the library)
 
 
+def _pkg():
+    global _package
+    if _package is None:
+        import importlib
+
+        _package = importlib.import_module(__package__)
+    return _package
+
+
 def rebase_gathered(gathered, world, rows, out=None):
     """`gathered` (int32 [world * rows, 2]): per rank rows - 1 {taskCount, firstTask} records with rank-local
     firstTask and one record holding the rank's visible count (uint64).  Adds the counts of the lower ranks to
@@ -141,6 +150,29 @@ def gather_draw_list_packed(cmds_packed, group=None, gathered=None, out=None):
         gathered = torch.empty((world * rows, 2), dtype=cmds_packed.dtype, device=cmds_packed.device)
     dist.all_gather_into_tensor(gathered, cmds_packed, group=group)
     return rebase_gathered(gathered, world, rows, out)
+
+
+def create_native_comm(device, group=None):
+    """An RCCL communicator of the library's own (mcull_rccl_comm_create) over the ranks of a torch.distributed group:
+    rank 0's unique id travels through the group (any backend), then every rank joins.  The communicator is what
+    gather_draw_list_native hands to the library; torch.distributed is only the courier of 128 bytes."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [_pkg().rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return _pkg().RcclComm(box[0], world, rank, device)
+
+
+def gather_draw_list_native(comm, stream, cmds_packed, gathered, out):
+    """gather_draw_list_packed with the collective inside the library (mcull_allgather_commands): ncclAllGather on the
+    caller's communicator and stream + the rebase launch, two enqueues from C++ with no tensor bookkeeping in between.
+    comm: RcclComm; stream: a torch.cuda.Stream; gathered [world * rows, 2] int32 and out [2, world] int64 are the
+    buffers a frame loop keeps.  Returns (totals_all, cmds_all) like gather_draw_list_packed."""
+    rows = cmds_packed.shape[0]
+    with torch.cuda.device(cmds_packed.device):
+        _pkg().allgather_commands(comm, stream.cuda_stream, cmds_packed.data_ptr(), gathered.data_ptr(), comm.world, rows - 1,
+                                    out[0].data_ptr(), out[1].data_ptr())
+    return out[0], gathered.view(comm.world, rows, 2)[:, : rows - 1, :]
 
 
 def merge_depth(depth, group=None):
