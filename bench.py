@@ -180,6 +180,14 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def loaded_hip_runtime():
+    """The HIP runtime this process already uses (torch's), found through the process's own mappings."""
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return ctypes.CDLL(line.split()[-1])
+    return ctypes.CDLL("libamdhip64.so")
+
+
 class Env:
     """Process-wide state shared by the workloads: ranks, the library, the timing primitives."""
 
@@ -222,8 +230,14 @@ class Env:
         # cull behind the previous step's collective instead of overlapping them.
         self.stream = torch.cuda.Stream(device=self.device)
         self.ctx = self.mc.Context(self.local_rank, stream=self.stream.cuda_stream)
+        # the step's collective goes through the library (mcull_allgather_commands on a communicator of its own, made
+        # from an id that torch.distributed carries to the ranks) unless --torch-collective asks for all_gather_into_tensor
+        self.native_comm = None
+        if self.multi and not args.rehearse_shared_gpu and not args.torch_collective:
+            with stdout_to_stderr():
+                self.native_comm = self.mdist.create_native_comm(self.local_rank)
         # HIP events on the stream the kernels are launched on, bracketing exactly the timed region
-        self.hip = ctypes.CDLL("libamdhip64.so.7")
+        self.hip = loaded_hip_runtime()
         self.ev0, self.ev1 = ctypes.c_void_p(), ctypes.c_void_p()
         assert self.hip.hipEventCreate(ctypes.byref(self.ev0)) == 0 and self.hip.hipEventCreate(ctypes.byref(self.ev1)) == 0
 
@@ -282,6 +296,9 @@ class Env:
             print(json.dumps(out), flush=True)
 
     def close(self):
+        if self.native_comm is not None:
+            torch.cuda.synchronize()
+            self.native_comm.close()
         if self.multi:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -509,6 +526,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
 
                 if args.rehearse_shared_gpu:
                     gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b].cpu())
+                elif env.native_comm is not None:
+                    gathered[b] = env.mdist.gather_draw_list_native(env.native_comm, comm, cmds_packed[b], gather_buf[b], gather_out[b])
                 else:
                     gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b], gathered=gather_buf[b], out=gather_out[b])
                 if gather_lists:
@@ -1110,6 +1129,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bounds-copies", type=int, default=64, help="bounds workload: copies of the kitten fixture")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank gather path even with one rank")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="multi-rank step: torch.distributed.all_gather_into_tensor + the library's rebase instead of mcull_allgather_commands")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="control-flow rehearsal only: all ranks share GPU 0, collectives over gloo on host copies")
     args = ap.parse_args()
