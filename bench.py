@@ -233,9 +233,14 @@ class Env:
         # the step's collective goes through the library (mcull_allgather_commands on a communicator of its own, made
         # from an id that torch.distributed carries to the ranks) unless --torch-collective asks for all_gather_into_tensor
         self.native_comm = None
+        self.collective = "torch.distributed all_gather_into_tensor + mcull_rebase_gathered_commands" if self.multi else None
         if self.multi and not args.rehearse_shared_gpu and not args.torch_collective:
-            with stdout_to_stderr():
-                self.native_comm = self.mdist.create_native_comm(self.local_rank)
+            try:
+                with stdout_to_stderr():
+                    self.native_comm = self.mdist.create_native_comm(self.local_rank)
+                self.collective = "mcull_allgather_commands (ncclAllGather + rebase enqueued by the library on its own RCCL communicator)"
+            except Exception as e:  # noqa: BLE001 - RCCL not found at run time, or the communicator refused: the torch path still works
+                print("bench: native collective unavailable (%s); using torch.distributed" % e, file=sys.stderr)
         # HIP events on the stream the kernels are launched on, bracketing exactly the timed region
         self.hip = loaded_hip_runtime()
         self.ev0, self.ev1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -243,6 +248,9 @@ class Env:
 
     def fence(self):
         if self.multi:
+            # the barrier runs on torch.distributed's communicator, the steps' gathers on the library's: drain the device
+            # first, so that kernels of the two communicators are never in flight together
+            torch.cuda.synchronize()
             self.dist.barrier()
         torch.cuda.synchronize()
 
@@ -483,6 +491,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         ev_comm = [torch.cuda.Event() for _ in range(2)]
         main = env.stream
 
+    native = [env.native_comm]  # set to None below if its first result is not what torch.distributed's gather gives
+
     host_s = [0.0, 0.0, 0]  # MCULL_BENCH_HOST_TIMES=1: host seconds spent enqueuing the culls / the gathers, steps
 
     def step(k, record=False, gather_lists=False):
@@ -526,8 +536,8 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
 
                 if args.rehearse_shared_gpu:
                     gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b].cpu())
-                elif env.native_comm is not None:
-                    gathered[b] = env.mdist.gather_draw_list_native(env.native_comm, comm, cmds_packed[b], gather_buf[b], gather_out[b])
+                elif native[0] is not None:
+                    gathered[b] = env.mdist.gather_draw_list_native(native[0], comm, cmds_packed[b], gather_buf[b], gather_out[b])
                 else:
                     gathered[b] = env.mdist.gather_draw_list_packed(cmds_packed[b], gathered=gather_buf[b], out=gather_out[b])
                 if gather_lists:
@@ -539,6 +549,21 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         if record:
             kernel_ms.append(ms)
 
+    if multi and native[0] is not None:
+        # once, untimed: the library's collective against torch.distributed's on the same commands; a rank that sees a
+        # difference takes every rank back to the torch path (and the line says which one ran)
+        torch.cuda.synchronize()
+        step(0)
+        torch.cuda.synchronize()
+        ref_totals, ref_cmds = env.mdist.gather_draw_list_packed(cmds_packed[0])
+        same = torch.equal(ref_totals, gathered[0][0]) and torch.equal(ref_cmds, gathered[0][1])
+        flag = torch.tensor([1 if same else 0], device=device, dtype=torch.int32)
+        env.dist.all_reduce(flag, op=env.dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            print("bench: mcull_allgather_commands disagreed with torch.distributed on rank %d; using torch.distributed" % rank, file=sys.stderr)
+            native[0] = None
+            env.collective = "torch.distributed all_gather_into_tensor + mcull_rebase_gathered_commands (the native collective's first result differed)"
+        torch.cuda.synchronize()
     elapsed, dev_ms = env.timed(step, steps=steps, warmup=warmup)
     region_ms_per_step = dev_ms / steps
     if os.environ.get("MCULL_BENCH_HOST_TIMES") and rank == 0:
@@ -627,6 +652,7 @@ def run_cull(env, workload):
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / max(n_pairs, 1), 4),
                      **({"pairs_reaching_hiz": r["hiz_pairs"]} if r["hiz_pairs"] else {}),
                      "instance_precull": r["precull"],
+                     **({"collective": env.collective} if multi else {}),
                      "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % shard_note)
                      if multi else "single GPU"}
         if workload == "config5":

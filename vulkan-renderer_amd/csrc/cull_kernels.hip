@@ -1916,10 +1916,17 @@ __device__ __forceinline__ void emit_commands_body(
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
     uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
     uint32_t *__restrict__ tile_counts, uint32_t n_tiles, const unsigned long long *__restrict__ tile_offsets,
-    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w) {
+    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w,
+    uint32_t *__restrict__ work_header = nullptr) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     // every consumer of the tile counters has finished (stream order): leave them zero for the next cull
     if (tile_counts && i < n_tiles) tile_counts[i] = 0;
+    // ... and of the instance level's work list: its length moves to word 1 (what mcull_precull_stats reads) and word
+    // 0, which the next cull's pre-pass reserves from, is zero again without a launch of its own
+    if (work_header && i == 0) {
+        work_header[1] = work_header[0];
+        work_header[0] = 0u;
+    }
     if (i >= n_instances) return;
     unsigned long long base = 0;
     if (rank_totals)
@@ -1974,9 +1981,10 @@ __global__ __launch_bounds__(kBlock) void emit_commands_kernel(
     const uint64_t *__restrict__ total, const uint64_t *__restrict__ rank_totals, uint32_t rank,
     uint32_t stride, uint32_t offset, uint32_t form, uint8_t *__restrict__ commands,
     uint32_t *__restrict__ tile_counts, uint32_t n_tiles, const unsigned long long *__restrict__ tile_offsets,
-    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w) {
+    const uint32_t *__restrict__ group_base, uint32_t groups_per_instance, uint32_t *__restrict__ inst_first_w,
+    uint32_t *__restrict__ work_header) {
     emit_commands_body(ranges, next_nonempty, uniform_count, n_instances, inst_first, inst_count, total, rank_totals, rank, stride, offset,
-                       form, commands, tile_counts, n_tiles, tile_offsets, group_base, groups_per_instance, inst_first_w);
+                       form, commands, tile_counts, n_tiles, tile_offsets, group_base, groups_per_instance, inst_first_w, work_header);
 }
 
 // ordered mode only
@@ -2191,9 +2199,11 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
     // 256 CUs for small ones
 #define MCULL_MASK_T(NG_, NT_) launch_cull_mask_t<NG_, NT_>(s, v, mask, tile_counts, view_dev, work, kept_report, flags, list_of_groups, est_groups, st)
     if (streaming) {
-        // a work list expected to be short is spread over twice as many waves: 211 000 listed groups of the 100 M-pair
-        // scene with its occlusion test on, 0.230 -> 0.221 ms per step (the 1.06 M groups listed without it: four per wave)
-        const bool short_list = work && !flags && est_groups && est_groups < (1u << 18);
+        // a work list expected to be short, with the occlusion test on, is spread over twice as many waves: 211 000 listed
+        // groups of the 100 M-pair scene, 0.230 -> 0.221 ms per step (the 1.06 M groups listed without it: four per wave).
+        // Without the occlusion test a short list keeps four per wave too (133 000 listed groups of a 12.5 M-pair shard:
+        // 0.0945 -> 0.0916 ms per step).
+        const bool short_list = work && !flags && est_groups && est_groups < (1u << 18) && (v.tests & MCULL_TEST_HIZ);
         if (s.n_groups >= (1u << 16) && !short_list) MCULL_MASK_T(4, true);
         else MCULL_MASK_T(2, true);
     } else {
@@ -2336,7 +2346,7 @@ hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint3
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
                                 uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st,
-                                const uint64_t *tile_offsets, uint32_t *inst_first_w) {
+                                const uint64_t *tile_offsets, uint32_t *inst_first_w, uint32_t *work_header) {
     if (!skips_empty_tiles(s)) tile_offsets = nullptr;  // the scatter pass has written every instance's offset itself
     const uint32_t n_tiles = (tile_counts || tile_offsets) ? tile_count_for(s.n_groups) : 0;
     const uint32_t work = s.n_instances > n_tiles ? s.n_instances : n_tiles;
@@ -2345,7 +2355,7 @@ hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const
     hipLaunchKernelGGL(emit_commands_kernel, dim3(grid), dim3(kBlock), 0, st, s.ranges, s.next_nonempty, uniform_count, s.n_instances,
                        inst_first, inst_count, total, rank_totals, rank, lay.stride, lay.offset, lay.form,
                        (uint8_t *)commands, tile_counts, n_tiles, (const unsigned long long *)tile_offsets, s.group_base,
-                       s.groups_per_instance, inst_first_w);
+                       s.groups_per_instance, inst_first_w, work_header);
     return hipGetLastError();
 }
 

@@ -172,6 +172,7 @@ struct mcull_ctx {
         DevBuf mask, tile_counts, tile_offsets, inst_first, inst_count, total, list, commands, work, group_work;
         uint64_t commands_layout = 0;  // stride/offset the context-owned command buffer was last zeroed for
         bool counters_clean = false;   // tile counters are all zero (the mask pass adds into them, the command pass re-zeroes)
+        bool work_clean = false;       // word 0 of the work list is zero (the pre-pass reserves from it, the command pass re-zeroes)
         uint64_t *total_ptr = nullptr;  // where the last cull wrote its count (context- or caller-owned)
         Last last;                      // description of the last cull (for rebase / downloads / payloads)
         bool counts_slow_pairs = false; // the last cull counted the pairs that left the fast predicate forms
@@ -930,7 +931,15 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             const bool ranged = c->have_ranges;
             if ((rc = ensure_range_spheres(c, s, plan->uniform_count))) return rc;
             plan->precull_units = ranged ? s.n_groups : c->n_instances;
-            if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
+            {
+                const void *before = o.work.p;
+                if ((rc = ensure(c, o.work, mcull::work_list_bytes(plan->precull_units, ranged)))) return rc;
+                // a new buffer, or a cull whose enqueue failed half way: the header starts at zero; otherwise the last
+                // cull's command pass has left word 0 zero
+                if (o.work.p != before) o.work_clean = false;
+                if (!o.work_clean) HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.work.p, 2, c->stream));
+                o.work_clean = false;  // until the command pass that re-zeroes it has been enqueued
+            }
             plan->work = (uint32_t *)o.work.p;
             // The pre-pass also tells the mask pass which instances need no frustum / no occlusion test (two bits in the
             // work list's entries) where that arithmetic is what the pass waits for: cache-resident bounds (1 M instances of
@@ -986,8 +995,9 @@ int launch_ordered_tail(mcull_ctx *c, mcull_ctx::ViewOut &o, const CullPlan &pl)
     HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, (const uint32_t *)o.inst_first.p, nullptr,
                                           (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands,
                                           (uint32_t *)o.tile_counts.p, c->stream,
-                                          pl.two_level ? (const uint64_t *)o.tile_offsets.p : nullptr, (uint32_t *)o.inst_first.p));
+                                          pl.two_level ? (const uint64_t *)o.tile_offsets.p : nullptr, (uint32_t *)o.inst_first.p, pl.work));
     o.counters_clean = true;
+    if (pl.work) o.work_clean = true;
     return MCULL_OK;
 }
 
@@ -1052,7 +1062,7 @@ int cull_impl(mcull_ctx *c, const mcull_globals *g, const mcull_globals *g_dev, 
         const bool hand_on = pl.work && pl.hand_on;
         if (pl.work) {
             // the mask pass will cover the work list's groups only: every other ballot is zero from here
-            HIPCHK(c, mcull::launch_zero_words(pl.work, 1, c->stream));
+            // (the list's length word is zero: the last cull's command pass, or the allocation, left it so)
             // few groups per instance: the pre-pass zeroes the dropped groups' ballots itself; many: one memset
             const bool inline_zero = pl.s.n_groups <= 8ull * pl.s.n_instances;
             if (!inline_zero) HIPCHK(c, mcull::launch_zero_words((uint32_t *)o.mask.p, pl.s.n_groups * 2, c->stream));
@@ -1439,7 +1449,7 @@ int mcull_precull_stats(mcull_ctx *c, uint64_t *instances_or_groups_marked, uint
     if (!o.last.work) return MCULL_OK;  // the pre-cull did not run for this cull
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t kept = 0;  // the list's length is the number of survivors
-    HIPCHK(c, hipMemcpyAsync(&kept, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&kept, o.last.work + 1, 4, hipMemcpyDeviceToHost, c->stream));  // word 1: see emit_commands_body
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t n = o.last.precull_units - kept;
     if (instances_or_groups_marked) *instances_or_groups_marked = n;
@@ -1455,7 +1465,7 @@ int mcull_precull_group_stats(mcull_ctx *c, uint64_t *groups_dropped, uint64_t *
     if (!o.last.group_work) return MCULL_OK;  // the group level did not run for this cull
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t listed = 0, kept = 0;  // entries the instance level handed over, groups that survived
-    HIPCHK(c, hipMemcpyAsync(&listed, o.last.work, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&listed, o.last.work + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&kept, o.last.group_work, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t tested = o.last.scene.group_rec ? (uint64_t)listed : (uint64_t)listed * o.last.scene.groups_per_instance;

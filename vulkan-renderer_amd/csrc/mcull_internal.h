@@ -150,7 +150,10 @@ hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint3
 hipError_t launch_emit_commands(const SceneDev &s, uint32_t uniform_count, const uint32_t *inst_first,
                                 const uint32_t *inst_count, const uint64_t *total, const uint64_t *rank_totals,
                                 uint32_t rank, CmdLayout lay, void *commands, uint32_t *tile_counts, hipStream_t st,
-                                const uint64_t *tile_offsets = nullptr, uint32_t *inst_first_w = nullptr);
+                                const uint64_t *tile_offsets = nullptr, uint32_t *inst_first_w = nullptr,
+                                uint32_t *work_header = nullptr);
+// work_header: the instance level's work list of this cull (or nullptr); the command pass moves its length to word 1
+// and leaves word 0 zero for the next cull's pre-pass
 // tile_offsets (with inst_first_w = the same array as inst_first): the scatter pass ran with tile offsets and skipped the
 // tiles without a visible pair; the command pass then takes the offsets of the instances that begin in such a tile from
 // the tile offsets and stores them into inst_first_w.
