@@ -594,6 +594,19 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                           "list_bytes_per_rank": int(totals_all.max()) * 8 * world}
     pre_marked, pre_tested, pre_per_group = ctx.precull_stats()  # of the last timed cull (view slot 0)
     grp_dropped, grp_tested = ctx.precull_group_stats()
+    if os.environ.get("MCULL_BENCH_GROUP_CENSUS") and workload == "config3" and rank == 0:
+        # experiment: of the groups the mask pass was handed, how many hold a meshlet that passes frustum + occlusion?
+        for t in (tests & ~mc.TEST_CONE, tests):
+            ctx.cull(views[0], tests=t, write_mask=True, list_ptr=lst.data_ptr(), list_capacity=cap, commands_ptr=cmds[1].data_ptr(),
+                     total_ptr=total[1].data_ptr())
+            env.fence()
+            m = ctx.download_mask()
+            gd, gt = ctx.precull_group_stats()
+            pm, pt, _ = ctx.precull_stats()
+            full = int((m == np.uint64(0xffffffffffffffff)).sum())
+            print("census tests=%d: groups %d, instance level kept %d of %d instances, group level handed %d, listed %d, "
+                  "groups with a visible meshlet %d (all 64 visible: %d), visible pairs %d"
+                  % (t, m.size, pt - pm, pt, gt, gt - gd, int((m != 0).sum()), full, int(total[1].item())), file=sys.stderr)
     hiz_pairs = 0
     if use_hiz and workload == "config4":
         # pairs that reach the occlusion test (one 4-byte texel each in the algorithmic bytes): the survivors

@@ -754,7 +754,30 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
     uint32_t k = 0;
     while (k < 16u && (((x_hi >> k) - (x_lo >> k)) > 3 || ((y_hi >> k) - (y_lo >> k)) > 3)) k++;
     const uint32_t lw = v.w0 >> k, lh = v.h0 >> k;
-    if (v.level_table[48] == 0u && k < 16u && (uint32_t)(x_hi >> k) < lw && (uint32_t)(y_hi >> k) < lh) {
+    if (v.level_table[48] != 0u) return 0u;
+    // A rectangle that needs a level coarser than the window tables' cells: the tables' windows cover it within one cell
+    // each way (see kHizWinBase), where 4 x 4 texels of level k may reach twice as far - and every level-0 texel they
+    // reach beyond the rectangle that is background undoes the proof.
+    if (v.windows && k > kHizWinBase && v.level_table[kHizWinWord] != 0u) {
+        const uint32_t cw = v.w0 >> kHizWinBase, ch = v.h0 >> kHizWinBase;
+        const int32_t X0 = x_lo >> kHizWinBase, X1 = x_hi >> kHizWinBase, Y0 = y_lo >> kHizWinBase, Y1 = y_hi >> kHizWinBase;
+        const uint32_t W = (uint32_t)(X1 - X0 + 1), H = (uint32_t)(Y1 - Y0 + 1);
+        uint32_t j = 31u - (uint32_t)__clz((int)min(W, H));  // W, H >= 1
+        j = min(j, v.win_levels);
+        const uint32_t win = 1u << j, nx = (W + win - 1u) >> j, ny = (H + win - 1u) >> j;
+        if ((uint32_t)X1 < cw && (uint32_t)Y1 < ch && nx <= 4u && ny <= 4u) {
+            const float *table = j == 0u ? v.pyramid + v.level_table[32 + kHizWinBase] : v.windows + (size_t)(j - 1u) * cw * ch;
+            const int32_t xl = X1 - (int32_t)win + 1, yl = Y1 - (int32_t)win + 1;  // the last window's corner; >= X0, Y0
+            float dmin = __builtin_inff();
+#pragma unroll
+            for (int32_t b = 0; b < 4; b++)
+#pragma unroll
+                for (int32_t a = 0; a < 4; a++)
+                    dmin = fminf(dmin, table[(size_t)min(Y0 + b * (int32_t)win, yl) * cw + min(X0 + a * (int32_t)win, xl)]);
+            return nz_ub < dmin - 0.05f ? kInstCulled : 0u;
+        }
+    }
+    if (k < 16u && (uint32_t)(x_hi >> k) < lw && (uint32_t)(y_hi >> k) < lh) {
         const float *level = v.pyramid + v.level_table[32 + k];
         const int32_t x0 = x_lo >> k, x1 = x_hi >> k, y0 = y_lo >> k, y1 = y_hi >> k;
         float dmin = __builtin_inff();

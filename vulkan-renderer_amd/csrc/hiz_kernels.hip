@@ -35,6 +35,7 @@ __device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y
 __device__ __forceinline__ void publish_nan_word(uint32_t *__restrict__ nan_seen) {
     nan_seen[0] = __hip_atomic_load(nan_seen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nan_seen[1] = 0u;
+    nan_seen[kHizWinWord - kHizNanWord] = 0u;  // window tables made from an earlier build describe another image
 }
 __device__ __forceinline__ float min4(float d0, float d1, float d2, float d3) {
     return glsl_min(glsl_min(d0, d1), glsl_min(d2, d3));  // shader.comp:28
@@ -488,6 +489,44 @@ size_t hiz_strip_floats(uint32_t w, uint32_t h) {
         ch = (ch + 1u) >> 1;
     }
     return n;
+}
+
+// One table of sliding-window minima from the one before it (see kHizWinBase): next(x, y) = min of prev at (x, y),
+// (x + half, y), (x, y + half), (x + half, y + half) wherever all four exist.  prev is the pyramid level itself for the
+// first table.  `done` (the last table's launch only): the word that tells the culls the tables are complete.
+__global__ __launch_bounds__(kBlock) void hiz_window_kernel(const float *__restrict__ prev, float *__restrict__ next, uint32_t cw,
+                                                            uint32_t ch, uint32_t half, uint32_t *__restrict__ done) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (done && i == 0) *done = 1u;
+    if (i >= cw * ch) return;
+    const uint32_t y = i / cw, x = i - y * cw;
+    if (x + 2u * half > cw || y + 2u * half > ch) return;
+    const float *p = prev + (size_t)y * cw + x;
+    next[i] = fminf(fminf(p[0], p[half]), fminf(p[(size_t)half * cw], p[(size_t)half * cw + half]));
+}
+
+uint32_t hiz_window_levels(uint32_t w, uint32_t h) {
+    const uint32_t cw = w >> kHizWinBase, ch = h >> kHizWinBase, least = cw < ch ? cw : ch;
+    uint32_t n = 0;
+    while (n < kHizWinMaxLevels && (2u << n) <= least) n++;
+    return n;
+}
+
+size_t hiz_window_floats(uint32_t w, uint32_t h) {
+    return (size_t)hiz_window_levels(w, h) * (w >> kHizWinBase) * (h >> kHizWinBase);
+}
+
+hipError_t launch_hiz_windows(const float *pyramid, uint32_t *level_table, uint32_t w, uint32_t h, uint64_t base_offset,
+                              float *windows, hipStream_t st) {
+    const uint32_t n = hiz_window_levels(w, h), cw = w >> kHizWinBase, ch = h >> kHizWinBase;
+    const float *prev = pyramid + base_offset;
+    for (uint32_t j = 1; j <= n; j++) {
+        float *next = windows + (size_t)(j - 1u) * cw * ch;
+        hipLaunchKernelGGL(hiz_window_kernel, dim3((cw * ch + kBlock - 1) / kBlock), dim3(kBlock), 0, st, prev, next, cw, ch, 1u << (j - 1u),
+                           j == n ? level_table + kHizWinWord : (uint32_t *)nullptr);
+        prev = next;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,

@@ -25,6 +25,8 @@ struct DevBuf {
 
 struct HizSlot {
     DevBuf pyramid, table, strips;  // strips: largest depth per 64 x 8 strip of the depth image (large images only)
+    DevBuf windows;                 // sliding-window minima (mcull::kHizWinBase), made by the first cull that wants them
+    bool windows_current = false;   // ... from the pyramid as it was last built through this context
     bool has_strips = false;
     uint32_t w = 0, h = 0, levels = 0;
     uint32_t lw[MCULL_MAX_HIZ_LEVELS], lh[MCULL_MAX_HIZ_LEVELS];
@@ -136,6 +138,7 @@ struct mcull_ctx {
     DevBuf view_dev;  // MCULL_MAX_VIEWS + 1 device-resident ViewConst records (the *_device_globals calls; the last one is the rasteriser's)
     uint32_t depth_w = 0, depth_h = 0;
     int hiz_mode = 0;  // pyramid scheme (see launch_hiz): 0 chosen by image size; 1-3 force one of the schemes
+    bool hiz_windows = true;  // MCULL_HIZ_WINDOWS=0: the instance and group levels prove occlusion from the pyramid's own levels only (measurements)
     bool hiz_strips = true;  // MCULL_HIZ_STRIPS=0: no strip maxima, every occlusion test reads its texel (measurements)
     bool precull_flags = true;  // MCULL_PRECULL_FLAGS=0: the instance level only drops instances, it narrows no tests (measurements)
     DevBuf view_flags;          // multi-view culls: one byte per instance and view slot (classify_views_kernel)
@@ -383,6 +386,7 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     // The pyramid scheme is chosen by image size (launch_hiz); these switches force one of the schemes
     // for evaluation and tests (results are identical)
     if (const char *hs = std::getenv("MCULL_HIZ_STRIPS")) c->hiz_strips = hs[0] != '0';
+    if (const char *hw = std::getenv("MCULL_HIZ_WINDOWS")) c->hiz_windows = hw[0] != '0';
     if (const char *pf = std::getenv("MCULL_PRECULL_FLAGS")) c->precull_flags = pf[0] != '0';
     if (const char *pg = std::getenv("MCULL_PRECULL_GROUPS")) c->precull_groups = pg[0] != '0';
     if (const char *pe = std::getenv("MCULL_PRECULL_ESTIMATE")) c->precull_estimate = std::atoll(pe);
@@ -421,7 +425,7 @@ int mcull_destroy(mcull_ctx *c) {
         for (DevBuf *b : {&o.mask, &o.tile_counts, &o.tile_offsets, &o.inst_first, &o.inst_count, &o.total, &o.list, &o.commands, &o.work,
                            &o.group_work})
             release(*b);
-    for (auto &s : c->hiz) { release(s.pyramid); release(s.table); release(s.strips); }
+    for (auto &s : c->hiz) { release(s.pyramid); release(s.table); release(s.strips); release(s.windows); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->kept_host) (void)hipHostFree(const_cast<uint32_t *>(c->kept_host));
@@ -711,6 +715,7 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
         c->timed = true;
     }
     s.built = true;
+    s.windows_current = false;
     return MCULL_OK;
 }
 
@@ -958,6 +963,20 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 }
                 if ((rc = ensure(c, o.group_work, mcull::work_list_bytes(s.n_groups, ranged)))) return rc;
                 plan->group_work = (uint32_t *)o.group_work.p;
+                // many groups per instance and the occlusion test on: the two levels' proofs get the window tables of
+                // the pyramid (made here when the pyramid has been rebuilt since; 7 small launches)
+                HizSlot &hs = c->hiz[p.hiz_view];
+                const uint32_t win_levels = (p.tests & MCULL_TEST_HIZ) && c->hiz_windows ? mcull::hiz_window_levels(hs.w, hs.h) : 0u;
+                if (win_levels && hs.levels > mcull::kHizWinBase) {
+                    if ((rc = ensure(c, hs.windows, mcull::hiz_window_floats(hs.w, hs.h) * 4))) return rc;
+                    if (!hs.windows_current) {
+                        HIPCHK(c, mcull::launch_hiz_windows((const float *)hs.pyramid.p, (uint32_t *)hs.table.p, hs.w, hs.h,
+                                                            hs.loff[mcull::kHizWinBase], (float *)hs.windows.p, c->stream));
+                        hs.windows_current = true;
+                    }
+                    plan->v.windows = (const float *)hs.windows.p;
+                    plan->v.win_levels = win_levels;
+                }
             }
             if (c->precull_adaptive && !o.probe_pending) {
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports

@@ -36,6 +36,10 @@ struct ViewConst {
     const float *strips;
     uint32_t strips_w;
     uint32_t strips_per_pair;  // the per-pair occlusion test consults them too (memory-bound passes; the instance level always may)
+    // sliding-window minima over the pyramid's level kHizWinBase (launch_hiz_windows), or nullptr; win_levels tables.
+    // Valid only while word kHizWinWord of level_table is non-zero (every pyramid build clears it).
+    const float *windows;
+    uint32_t win_levels;
     // the guarded-exact predicates: force_exact != 0 sends every pair through the IEEE expressions (measurements,
     // tests); slow_pairs != nullptr counts the pairs that had to leave the fast forms
     uint32_t force_exact;
@@ -193,6 +197,20 @@ size_t depth_raster_scratch_bytes();  // device memory launch_depth_raster needs
 // between builds).
 constexpr size_t kHizCounterBytes = 2048;
 constexpr uint32_t kHizTableWords = 64, kHizNanWord = 48;
+// SLIDING-WINDOW MINIMA for the instance and group levels of a cull (no counterpart in the reference): with C = level
+// kHizWinBase of the pyramid (cw x ch cells of 2^kHizWinBase pixels square), table j = 1 .. win_levels holds, for every
+// cell (x, y) with x + 2^j <= cw and y + 2^j <= ch, the minimum of the 2^j x 2^j cells whose top-left one it is; row
+// length cw, ch rows per table, table j at float offset (j - 1) cw ch.  A rectangle of cells is then covered exactly by a
+// few overlapping windows (at most 4 x 4 of side 2^floor(log2(its shorter side)) when its sides differ by less than a
+// factor of four), where the pyramid's own coarser levels cover up to twice its extent each way.  Built on demand by a cull
+// that wants them; word kHizWinWord of the level table is cleared by every pyramid build and set by the launch that
+// finishes the tables, so a cull that finds it zero - a pyramid rebuilt since, e.g. by a replayed graph - does without.
+constexpr uint32_t kHizWinBase = 3, kHizWinMaxLevels = 7, kHizWinWord = 51;
+uint32_t hiz_window_levels(uint32_t w, uint32_t h);  // 0: the image is too small for any table
+size_t hiz_window_floats(uint32_t w, uint32_t h);
+// pyramid / level_table of a finished build (stream order); windows: hiz_window_floats(w, h) floats
+hipError_t launch_hiz_windows(const float *pyramid, uint32_t *level_table, uint32_t w, uint32_t h, uint64_t base_offset,
+                              float *windows, hipStream_t st);
 // `strips` (optional): hiz_strip_floats(w, h) floats - the largest depth of every 64 x 8 strip of the image, row by row
 // ((w + 63) / 64 per row), then of every 64 x 64 block (same row length; a block is written when its pixels lie inside
 // [0, 512 ceil((w >> 3) / 64)) x [0, 512 ceil((h >> 3) / 64)), the cover of the second launch's tiles); written only
