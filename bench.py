@@ -604,6 +604,9 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
             gd, gt = ctx.precull_group_stats()
             pm, pt, _ = ctx.precull_stats()
             full = int((m == np.uint64(0xffffffffffffffff)).sum())
+            per_inst = (m.reshape(n_inst, -1) != 0)
+            print("census tests=%d: instances with a visible meshlet %d, with every group holding one %d"
+                  % (t, int(per_inst.any(1).sum()), int(per_inst.all(1).sum())), file=sys.stderr)
             print("census tests=%d: groups %d, instance level kept %d of %d instances, group level handed %d, listed %d, "
                   "groups with a visible meshlet %d (all 64 visible: %d), visible pairs %d"
                   % (t, m.size, pt - pm, pt, gt, gt - gd, int((m != 0).sum()), full, int(total[1].item())), file=sys.stderr)

@@ -18,6 +18,7 @@
 //                emit_commands_kernel -> {taskCount, firstTask} per instance
 //   wave/block atomic  cull_atomic_kernel: ballot + mbcnt prefix, one atomic per wavefront (or per
 //                workgroup step), list order unspecified.
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -552,13 +553,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 // R = +inf: such a range is never pre-culled.
 // rmax[i] >= every meshlet radius of the range (what bounds the mip level its meshlets can select); +inf with R,
 // and when a radius of the range is negative (the sign of the projected radius then differs inside the range).
+// boxes[i] = {hx, hy, hz, 0}: no meshlet CENTRE of the range is farther than h from C along a mesh-space axis (rounded up;
+// +inf with R) - the box that a flat or elongated mesh fills far better than the sphere (range_boxes).
 // sliding: sphere i encloses the meshlets [i, i + 64) of an array of uniform_count meshlets instead - whatever group
 // of at most 64 meshlets starts at meshlet i, of any range, lies inside it.
 __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__restrict__ centre_radius,
                                                               const uint2 *__restrict__ ranges, uint32_t uniform_count,
                                                               uint32_t sliding, float4 *__restrict__ spheres,
-                                                              float *__restrict__ rmax) {
-    __shared__ float s_red[kWaves][4];
+                                                              float *__restrict__ rmax, float4 *__restrict__ boxes) {
+    __shared__ float s_red[kWaves][6];
     const uint32_t i = blockIdx.x;
     uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
     if (sliding) {
@@ -570,6 +573,8 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
         if (threadIdx.x == 0) {
             spheres[i] = make_float4(0.0f, 0.0f, 0.0f, count ? __builtin_inff() : 0.0f);
             rmax[i] = count ? __builtin_inff() : 0.0f;
+            const float h = count ? __builtin_inff() : 0.0f;
+            boxes[i] = make_float4(h, h, h, 0.0f);
         }
         return;
     }
@@ -594,30 +599,36 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
     bad = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
     __syncthreads();
     // any point works as the centre; what must hold is the radius, measured from the centre as stored
-    float r = 0.0f, rm = 0.0f;
+    float r = 0.0f, rm = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
     for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
         const float4 c = centre_radius[first + j];
         const float dx = c.x - cx, dy = c.y - cy, dz = c.z - cz;
         // |c - C| + r, each step rounded to nearest: the factor below covers those roundings
         r = fmaxf(r, sqrtf((dx * dx + dy * dy) + dz * dz) + fabsf(c.w));
         rm = fmaxf(rm, fabsf(c.w));
+        hx = fmaxf(hx, fabsf(dx)); hy = fmaxf(hy, fabsf(dy)); hz = fmaxf(hz, fabsf(dz));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         r = fmaxf(r, __shfl_xor(r, d, 64));
         rm = fmaxf(rm, __shfl_xor(rm, d, 64));
         neg = fmaxf(neg, __shfl_xor(neg, d, 64));
+        hx = fmaxf(hx, __shfl_xor(hx, d, 64)); hy = fmaxf(hy, __shfl_xor(hy, d, 64)); hz = fmaxf(hz, __shfl_xor(hz, d, 64));
     }
-    if (lane == 0) { s_red[wave][0] = r; s_red[wave][1] = rm; s_red[wave][2] = neg; }
+    if (lane == 0) { s_red[wave][0] = r; s_red[wave][1] = rm; s_red[wave][2] = neg; s_red[wave][3] = hx; s_red[wave][4] = hy; s_red[wave][5] = hz; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        r = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
-        rm = fmaxf(fmaxf(s_red[0][1], s_red[1][1]), fmaxf(s_red[2][1], s_red[3][1]));
-        neg = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
+        auto top = [&](int k) { return fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k])); };
+        r = top(0); rm = top(1); neg = top(2);
         r = r * 1.00001f + 1.0e-30f;
         if (bad != 0.0f || !(r < 1.0e18f)) r = __builtin_inff();
         spheres[i] = make_float4(cx, cy, cz, r);
         rmax[i] = (neg != 0.0f || !(r < 1.0e18f)) ? __builtin_inff() : rm;
+        // the differences are rounded once each (relative 2^-24): the factor covers it
+        const float inf = __builtin_inff();
+        const bool ok = r < 1.0e18f;
+        boxes[i] = make_float4(ok ? top(3) * 1.00001f + 1.0e-30f : inf, ok ? top(4) * 1.00001f + 1.0e-30f : inf,
+                               ok ? top(5) * 1.00001f + 1.0e-30f : inf, 0.0f);
     }
 }
 
@@ -648,7 +659,7 @@ __host__ __device__ inline size_t work_rec_offset_words(uint64_t units) { return
 //           radius is then never positive);
 //   texel:  u, v inside [u_lo, u_hi] x [v_lo, v_hi], a sub-range of (0, 1): no REPEAT wrap.  Level l's texel
 //           x = floor(u (w0 >> l)) is the minimum over the level-0 columns [x 2^l, (x+1) 2^l) (the 2x2 reduction
-//           of floor-halved levels nests exactly), and these lie inside [u w0 - 2 2^l, u w0 + 2^l].
+//           of floor-halved levels nests exactly), and these lie inside [u w0 - 2^l - (w0 mod 2^l), u w0 + 2^l].
 // So every texel any meshlet can select is a minimum over level-0 texels inside a known rectangle, hence not
 // below dmin, the minimum of the texels of one coarser level k that cover the rectangle (at most 4 x 4 reads;
 // levels drop the odd last column and row of their source, so the rectangle must lie inside level k's cover).
@@ -666,8 +677,32 @@ constexpr uint32_t kInstCulled = 1u;  // every meshlet is certainly rejected
 constexpr uint32_t kInstInside = 2u;  // no meshlet is rejected by the frustum test
 constexpr uint32_t kInstOpen = 4u;    // no meshlet is rejected by the occlusion test
 
-__device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float wx, float wy, float wz, float rho, float rmax_w,
-                                                       bool want_open) {
+// what instance_classify needs of an instance, whatever the view: world-space sphere centre, the bound F on the
+// stretch of its matrix, the range's radius and largest meshlet radius, and the magnitudes the margins scale with
+// BOX: also the world-space images of the box's half axes, b[i] = column i of the matrix times h_i, and hs = F (hx + hy + hz)
+struct InstanceGeom {
+    float wx, wy, wz, F, R, rmax_local, ax, ay, az;
+    float b[3][3], hs;
+};
+
+// where launch_range_spheres / launch_group_spheres put the boxes of n ranges: behind the n spheres and n largest radii
+__host__ __device__ inline size_t range_box_offset_bytes(uint32_t n) { return ((size_t)n * 20 + 15) & ~(size_t)15; }
+__host__ __device__ inline const float4 *range_boxes(const float4 *spheres, uint32_t n) {
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + range_box_offset_bytes(n));
+}
+
+// how far the box reaches from its centre along (nx, ny, nz), not necessarily a unit vector: sum_i |n . b_i|.  Each dot
+// product is off by a few 2^-24 of |n| |b_i| <= |n| F h_i; the caller adds |n| hs 2^-18 for that.
+__device__ __forceinline__ float box_reach(const InstanceGeom &q, float nx, float ny, float nz) {
+    return (fabsf((nx * q.b[0][0] + ny * q.b[0][1]) + nz * q.b[0][2]) + fabsf((nx * q.b[1][0] + ny * q.b[1][1]) + nz * q.b[1][2])) +
+           fabsf((nx * q.b[2][0] + ny * q.b[2][1]) + nz * q.b[2][2]);
+}
+
+// BOX: geo also holds the range's box; a clip coordinate of a meshlet centre then differs from the centre's by at most the
+// box's reach along that row of VP (box_reach), plus the same roundoff terms - whichever bound is smaller is used.
+template <bool BOX>
+__device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, const InstanceGeom &geo, float rho, float rmax_w, bool want_open) {
+    const float wx = geo.wx, wy = geo.wy, wz = geo.wz;
     float c[4], e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -676,6 +711,12 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
         const float len = v.vp_row_len[k];  // >= |row k of the linear part|
         const float mag = ((fabsf(m0) * (fabsf(wx) + rho) + fabsf(m1) * (fabsf(wy) + rho)) + fabsf(m2) * (fabsf(wz) + rho)) + fabsf(m3);
         e[k] = len * rho * 1.0001f + mag * 1.52587890625e-5f;  // 2^-16: a thousand times the roundoff of both evaluations
+        if (BOX) {
+            // centres as the per-meshlet path evaluates them: inside the box up to the roundoff of both evaluations
+            const float round_w = ((geo.ax + geo.ay) + geo.az) * 1.52587890625e-5f;
+            const float eb = (box_reach(geo, m0, m1, m2) * 1.0001f + len * (geo.hs * 3.814697265625e-6f + round_w)) + mag * 1.52587890625e-5f;
+            e[k] = fminf(e[k], eb);  // a box that is not finite gives NaN or +inf here: the sphere's bound stays
+        }
     }
     const float cw_lo = c[3] - e[3], cw_hi = c[3] + e[3];
     if (!(cw_lo > 1.0e-12f && cw_hi < 1.0e18f)) return 0u;
@@ -701,9 +742,12 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
         return 0u;
     }
     if ((v.w0 >> lmax) == 0u || (v.h0 >> lmax) == 0u || v.w0 > 32768u || v.h0 > 32768u) return 0u;
+    // (w0 >> l) 2^l = w0 - (w0 mod 2^l), and w0 mod 2^l <= w0 mod 2^lmax for l <= lmax: the second 2^l of the lower bound
+    // above is really that remainder - nothing for the usual image sizes, which halves the reach to the left and upwards
     const int32_t reach = 1 << lmax;
-    int32_t x_lo = (int32_t)floorf(u_lo * (float)v.w0) - 2 * reach - 2, x_hi = (int32_t)(u_hi * (float)v.w0) + reach + 2;
-    int32_t y_lo = (int32_t)floorf(v_lo * (float)v.h0) - 2 * reach - 2, y_hi = (int32_t)(v_hi * (float)v.h0) + reach + 2;
+    const int32_t rem_x = (int32_t)(v.w0 & (uint32_t)(reach - 1)), rem_y = (int32_t)(v.h0 & (uint32_t)(reach - 1));
+    int32_t x_lo = (int32_t)floorf(u_lo * (float)v.w0) - reach - rem_x - 2, x_hi = (int32_t)(u_hi * (float)v.w0) + reach + 2;
+    int32_t y_lo = (int32_t)floorf(v_lo * (float)v.h0) - reach - rem_y - 2, y_hi = (int32_t)(v_hi * (float)v.h0) + reach + 2;
     x_lo = max(x_lo, 0); y_lo = max(y_lo, 0);
     x_hi = min(x_hi, (int32_t)v.w0 - 1); y_hi = min(y_hi, (int32_t)v.h0 - 1);
     // Both tables are read with a fixed number of independent loads (coordinates past the rectangle repeat its last
@@ -809,13 +853,9 @@ __device__ __forceinline__ uint32_t instance_occlusion(const ViewConst &v, float
 // The same bound from the other side gives kInstInside: when (dot(n, W) + d) - reach - 2^-16 A > 0 for all five planes
 // and no radius of the range is negative, e_m >= 0 for every meshlet and the per-meshlet pass skips the frustum test.
 // want_more: also work out kInstInside / kInstOpen (the caller hands them on); otherwise only kInstCulled.
-// what instance_classify needs of an instance, whatever the view: world-space sphere centre, the bound F on the
-// stretch of its matrix, the range's radius and largest meshlet radius, and the magnitudes the margins scale with
-struct InstanceGeom {
-    float wx, wy, wz, F, R, rmax_local, ax, ay, az;
-};
-
-__device__ __forceinline__ InstanceGeom sphere_geometry(const float4 *__restrict__ transforms, uint32_t i, float4 sp, float rmax_local) {
+template <bool BOX = false>
+__device__ __forceinline__ InstanceGeom sphere_geometry(const float4 *__restrict__ transforms, uint32_t i, float4 sp, float rmax_local,
+                                                        float4 box = float4{0.0f, 0.0f, 0.0f, 0.0f}) {
     const float4 *t = transforms + (size_t)i * 4;
     const float4 c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];
     const float R = sp.w;
@@ -837,16 +877,32 @@ __device__ __forceinline__ InstanceGeom sphere_geometry(const float4 *__restrict
     const float ax = ((fabsf(c0.x) * ex + fabsf(c1.x) * ey) + fabsf(c2.x) * ez) + fabsf(c3.x);
     const float ay = ((fabsf(c0.y) * ex + fabsf(c1.y) * ey) + fabsf(c2.y) * ez) + fabsf(c3.y);
     const float az = ((fabsf(c0.z) * ex + fabsf(c1.z) * ey) + fabsf(c2.z) * ez) + fabsf(c3.z);
-    return InstanceGeom{wx, wy, wz, F, R, rmax_local, ax, ay, az};
+    InstanceGeom q{wx, wy, wz, F, R, rmax_local, ax, ay, az, {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}}, 0.0f};
+    if (BOX) {
+        q.b[0][0] = c0.x * box.x; q.b[0][1] = c0.y * box.x; q.b[0][2] = c0.z * box.x;
+        q.b[1][0] = c1.x * box.y; q.b[1][1] = c1.y * box.y; q.b[1][2] = c1.z * box.y;
+        q.b[2][0] = c2.x * box.z; q.b[2][1] = c2.y * box.z; q.b[2][2] = c2.z * box.z;
+        q.hs = F * ((box.x + box.y) + box.z);
+    }
+    return q;
 }
+
 
 __device__ __forceinline__ InstanceGeom instance_geometry(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
                                                           const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i) {
     const uint32_t k = per_instance_sphere ? i : 0u;
     return sphere_geometry(transforms, i, spheres[k], rmax[k]);
 }
+// ... with the range's box (boxes = range_boxes(spheres, number of ranges))
+__device__ __forceinline__ InstanceGeom instance_geometry_box(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
+                                                              const float *__restrict__ rmax, const float4 *__restrict__ boxes,
+                                                              uint32_t per_instance_sphere, uint32_t i) {
+    const uint32_t k = per_instance_sphere ? i : 0u;
+    return sphere_geometry<true>(transforms, i, spheres[k], rmax[k], boxes[k]);
+}
 
 // tests: the tests to reason about (v.tests, or fewer when a coarser level has already settled some)
+template <bool BOX = false>
 __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, const ViewConst &v, bool want_more, uint32_t tests) {
     const float wx = q.wx, wy = q.wy, wz = q.wz, F = q.F, R = q.R, rmax_local = q.rmax_local, ax = q.ax, ay = q.ay, az = q.az;
     bool outside = false, inside = rmax_local < 1.0e18f;  // +inf: a negative or non-finite radius in the range
@@ -855,8 +911,14 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
         for (int p = 0; p < 5; p++) {
             const float nx = v.frustum[p][0], ny = v.frustum[p][1], nz = v.frustum[p][2], d = v.frustum[p][3];
             const float nlen = v.plane_len[p];  // >= max(|n|, 1)
-            const float reach = nlen * F * R;
-            const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach;
+            const float reach_sphere = nlen * F * R;
+            float reach = reach_sphere;
+            if (BOX) {
+                // centres: within the box's reach along n of W; radii: r_m |col 0| <= rmax F.  (Not finite: the sphere's.)
+                const float rb = (box_reach(q, nx, ny, nz) * 1.0001f + nlen * q.hs * 3.814697265625e-6f) + (rmax_local * F) * 1.0001f;
+                reach = fminf(reach_sphere, rb);
+            }
+            const float A = (((fabsf(nx) * ax + fabsf(ny) * ay) + fabsf(nz) * az) + fabsf(d)) + reach_sphere;
             const float base = ((nx * wx + ny * wy) + nz * wz) + d, margin = A * 1.52587890625e-5f;  // 2^-16
             outside |= (base + reach) + margin < 0.0f;
             inside = inside && (base - reach) - margin > 0.0f;
@@ -871,7 +933,7 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
         // numbers, plus the roundoff of both evaluations (a few 2^-24 of ax + ay + az)
         const float rho = (F * R) * 1.0001f + ((ax + ay) + az) * 1.52587890625e-5f;
         const float rmax_w = (rmax_local * F) * 1.0001f;
-        const uint32_t o = instance_occlusion(v, wx, wy, wz, rho, rmax_w, want_more);
+        const uint32_t o = instance_occlusion<BOX>(v, q, rho, rmax_w, want_more);
         if (o & kInstCulled) return kInstCulled;
         flags |= o;
     }
@@ -879,9 +941,10 @@ __device__ __forceinline__ uint32_t classify_geometry(const InstanceGeom &q, con
 }
 
 __device__ __forceinline__ uint32_t instance_classify(const float4 *__restrict__ transforms, const float4 *__restrict__ spheres,
-                                                      const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t i,
-                                                      const ViewConst &v, bool want_more) {
-    return classify_geometry(instance_geometry(transforms, spheres, rmax, per_instance_sphere, i), v, want_more, v.tests);
+                                                      const float *__restrict__ rmax, uint32_t per_instance_sphere, uint32_t n_ranges,
+                                                      uint32_t i, const ViewConst &v, bool want_more) {
+    return classify_geometry<true>(instance_geometry_box(transforms, spheres, rmax, range_boxes(spheres, per_instance_sphere ? n_ranges : 1u),
+                                                         per_instance_sphere, i), v, want_more, v.tests);
 }
 
 // The pre-pass of a single-view cull: the WORK LIST of the mask pass (layout above; work[0] is zero on entry).
@@ -907,7 +970,7 @@ __global__ __launch_bounds__(kPreBlock) void instance_precull_kernel(const float
     uint32_t hand_on[kPreItems];  // kInstInside / kInstOpen in bits 30 and 31 of the survivor's list entries (want_flags)
 #pragma unroll
     for (int q = 0; q < kPreItems; q++) {
-        const uint32_t f = i0 + q < n_instances ? instance_classify(transforms, spheres, rmax, per_instance_sphere, i0 + q, v, want_flags != 0u)
+        const uint32_t f = i0 + q < n_instances ? instance_classify(transforms, spheres, rmax, per_instance_sphere, n_instances, i0 + q, v, want_flags != 0u)
                                                : kInstCulled;
         outside[q] = (f & kInstCulled) != 0u;
         hand_on[q] = want_flags ? (f & (kInstInside | kInstOpen)) << 29 : 0u;
@@ -968,6 +1031,7 @@ constexpr int kGrpItems = 4;
 template <bool RANGED>
 __global__ __launch_bounds__(kBlock) void group_precull_kernel(const float4 *__restrict__ transforms,
                                                                const float4 *__restrict__ gspheres, const float *__restrict__ grmax,
+                                                               const float4 *__restrict__ gboxes,
                                                                uint32_t groups_per_instance, uint64_t units, ViewConst v_arg,
                                                                const ViewConst *__restrict__ view_dev,
                                                                const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
@@ -1012,7 +1076,7 @@ __global__ __launch_bounds__(kBlock) void group_precull_kernel(const float4 *__r
             const uint32_t tests = v.tests & ~(((settled & 1u) ? (uint32_t)MCULL_TEST_FRUSTUM : 0u) | ((settled & 2u) ? (uint32_t)MCULL_TEST_HIZ : 0u));
             uint32_t f = 0u;
             if (tests & (MCULL_TEST_FRUSTUM | MCULL_TEST_HIZ))
-                f = classify_geometry(sphere_geometry(transforms, inst, gspheres[sphere], grmax[sphere]), v, true, tests);
+                f = classify_geometry<true>(sphere_geometry<true>(transforms, inst, gspheres[sphere], grmax[sphere], gboxes[sphere]), v, true, tests);
             if (f & kInstCulled) continue;
             settled |= ((f & kInstInside) ? 1u : 0u) | ((f & kInstOpen) ? 2u : 0u);
             keep[q] = 1u;
@@ -2230,6 +2294,10 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
         if (s.n_groups >= (1u << 16) && !short_list) MCULL_MASK_T(4, true);
         else MCULL_MASK_T(2, true);
     } else {
+        static const int force_ng = getenv("MCULL_MASK_NG") ? atoi(getenv("MCULL_MASK_NG")) : 0;
+        if (force_ng == 2) MCULL_MASK_T(2, false);
+        else if (force_ng == 1) MCULL_MASK_T(1, false);
+        else
         if (s.n_groups >= (1u << 16)) MCULL_MASK_T(4, false);
         else if (s.n_groups >= (1u << 14)) MCULL_MASK_T(2, false);
         else MCULL_MASK_T(1, false);
@@ -2401,13 +2469,13 @@ hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visib
 
 // spheres[i] for ranges[i] (n_ranges of them), or spheres[0] for [0, uniform_count) when ranges == nullptr
 // spheres: n_ranges float4 followed by n_ranges float (range_sphere_bytes)
-size_t range_sphere_bytes(uint32_t n_ranges) { return (size_t)n_ranges * 20; }
+size_t range_sphere_bytes(uint32_t n_ranges) { return range_box_offset_bytes(n_ranges) + (size_t)n_ranges * 16; }
 
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
                                 float4 *spheres, hipStream_t st) {
     if (n_ranges == 0) return hipSuccess;
     hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, 0u, spheres,
-                       reinterpret_cast<float *>(spheres + n_ranges));
+                       reinterpret_cast<float *>(spheres + n_ranges), const_cast<float4 *>(range_boxes(spheres, n_ranges)));
     return hipGetLastError();
 }
 
@@ -2416,7 +2484,7 @@ hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges
 hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st) {
     if (n_meshlets == 0) return hipSuccess;
     hipLaunchKernelGGL(range_sphere_kernel, dim3(n_meshlets), dim3(kBlock), 0, st, centre_radius, (const uint2 *)nullptr, n_meshlets, 1u,
-                       spheres, reinterpret_cast<float *>(spheres + n_meshlets));
+                       spheres, reinterpret_cast<float *>(spheres + n_meshlets), const_cast<float4 *>(range_boxes(spheres, n_meshlets)));
     return hipGetLastError();
 }
 
@@ -2448,10 +2516,10 @@ hipError_t launch_group_precull(const SceneDev &s, const float4 *gspheres, uint3
     const uint32_t walkers = blocks < 4096u ? (uint32_t)blocks : 4096u;
     if (ranged)
         hipLaunchKernelGGL(group_precull_kernel<true>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
-                           s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
+                           range_boxes(gspheres, n_meshlets), s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
     else
         hipLaunchKernelGGL(group_precull_kernel<false>, dim3(walkers), dim3(kBlock), 0, st, s.transforms, gspheres, grmax,
-                           s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
+                           range_boxes(gspheres, n_meshlets), s.groups_per_instance, s.n_groups, v, view_dev, in, out, in_report);
     return hipGetLastError();
 }
 
