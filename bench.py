@@ -706,9 +706,29 @@ def run_cull(env, workload):
                                              "frac": round(rate / HBM_PEAK_GBS, 4),
                                              "bounds_bytes_not_touched": int(n_views * dropped),
                                              "note": "every meshlet bound counted as read, as before the instance pre-cull existed"}
+        default_scene = not (args.no_precull or args.exact or args.tests is not None or args.meshlets_per_instance)
+        if workload == "config3" and world == 1 and default_scene and (n_inst, args.c3_mesh) == (1_000_000, "proxy"):
+            # the pass is bound by vector-instruction issue, not by bytes: that bound leads, the byte figure stays beside it
+            step_kernels = (("instance_precull_kernel", 1), ("group_precull_kernel", 1), ("cull_mask_kernel", 1), ("scan_tiles_kernel", 1),
+                            ("compact_kernel", 1), ("emit_commands_kernel", 1), ("zero_words_kernel", 1))
+            counted = pmc_valu("r03_bench_config3", step_kernels)
+            if counted:
+                hbm = out["roofline"]
+                out["roofline"] = valu_roofline(counted, k_ms, kernels)
+                out["roofline"]["hbm"] = hbm
+        if workload == "config5" and world == 1 and default_scene and not args.separate_views and (n_inst, per) == (781250, 128):
+            # the mask pass of the eight views alone is issue-bound; its duration comes from the committed kernel trace
+            counted = pmc_valu("r03_bench_config5", (("cull_mask_views_kernel", 1),))
+            rel = os.path.join("profiles", "r03_bench_config5_summary.json")
+            if counted and os.path.exists(os.path.join(ROOT, rel)):
+                with open(os.path.join(ROOT, rel)) as f:
+                    us = [row.get("avg_us") for name, row in json.load(f).items() if "cull_mask_views_kernel" in name]
+                if us and us[0]:
+                    out["roofline"]["mask_pass_valu"] = valu_roofline(counted, us[0] * 1e-3, "cull_mask_views_kernel (duration from %s)" % rel)
         if world == 1:
             out["roofline"]["measured_device_copy"] = measured_copy_gbs(device)
-            out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / out["roofline"]["measured_device_copy"], 4)
+            hbm_part = out["roofline"].get("hbm", out["roofline"])
+            out["roofline"]["frac_of_measured_copy"] = round(hbm_part["achieved"] / out["roofline"]["measured_device_copy"], 4)
         if r["with_lists"]:
             out["with_list_gather"] = r["with_lists"]
         if not args.no_cpu_baseline and world == 1:
@@ -746,6 +766,42 @@ def pmc_summary_bytes(tag, kernels):
         if any(k in name for k in kernels):
             total += row.get("fetch_bytes_corrected", 0) + row.get("write_bytes_corrected", 0)
     return (total or None), rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+
+
+SIMDS = 1024  # 256 CUs x 4 SIMDs; a SIMD issues one vector instruction of a wave per 4 cycles
+
+
+def pmc_valu(tag, kernels):
+    """Vector instructions (per wave, summed over the waves) of one launch of each of `kernels`, summed, and the clock
+    while they ran, from the committed rocprofv3 pass of the same command (profiles/<tag>_summary.json:
+    SQ_INSTS_VALU, and GRBM_GUI_ACTIVE over the dispatch's duration).  `kernels`: (substring, launches per step)."""
+    rel = os.path.join("profiles", "%s_summary.json" % tag)
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        summ = json.load(f)
+    insts, cycles, weight = 0.0, 0.0, 0.0
+    for name, row in summ.items():
+        for key, per_step in kernels:
+            if key in name and "valu_insts_per_launch" in row:
+                insts += row["valu_insts_per_launch"] * per_step
+                if "clock_mhz" in row:
+                    cycles += row["clock_mhz"] * row["valu_insts_per_launch"] * per_step
+                    weight += row["valu_insts_per_launch"] * per_step
+    if not insts or not weight:
+        return None
+    return {"valu_insts": insts, "clock_mhz": cycles / weight, "source": rel + " (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE)"}
+
+
+def valu_roofline(counted, kernel_ms, kernel_name):
+    """The issue-rate bound: `counted` vector instructions need counted x 4 cycles of the 1 024 SIMDs."""
+    peak = SIMDS * counted["clock_mhz"] * 1e6 / 4.0 / 1e9  # G wave-instructions per second
+    achieved = counted["valu_insts"] / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "valu", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+            "valu_insts_per_step": int(counted["valu_insts"]), "clock_mhz": round(counted["clock_mhz"], 1),
+            "counters_source": counted["source"]}
 
 
 def pmc_traffic(args, workload, n_inst, per):

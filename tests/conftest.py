@@ -64,6 +64,42 @@ def config1(O):
     return dict(globals=z["globals"].view(O.GLOBALS), transforms=z["transforms"].view(O.TRANSFORM))
 
 
+class Forced:
+    """The library's evaluation switches (MCULL_* environment variables, read when a context is created) that the whole
+    test run was started under.  The parity tests run under whatever is forced and compare outputs only; assertions on
+    mechanism statistics (how many groups a level looked at, whether a level backed off) ask here whether the run has
+    taken that mechanism away, and then expect what the switch leaves or skip."""
+
+    def __init__(self):
+        self.env = {k: v for k, v in os.environ.items() if k.startswith("MCULL_")}
+
+    def off(self, name):
+        return self.env.get(name, "")[:1] == "0"
+
+    def on(self, name):
+        return self.env.get(name, "")[:1] == "1"
+
+    @property
+    def streaming(self):  # the kernels for bounds larger than the caches: no verdicts handed on, hence no group level
+        return self.on("MCULL_FORCE_STREAMING")
+
+    @property
+    def group_level(self):
+        return not (self.off("MCULL_PRECULL_GROUPS") or self.off("MCULL_PRECULL_FLAGS") or self.streaming)
+
+    @property
+    def adaptive(self):
+        return not self.off("MCULL_PRECULL_ADAPTIVE")
+
+
+FORCED = Forced()  # at import: before any test changes the environment for a context of its own
+
+
+@pytest.fixture(scope="session")
+def forced():
+    return FORCED
+
+
 @pytest.fixture(scope="session")
 def _shared_ctx(mc):
     # the instance pre-cull from 2048 groups on (the library's own threshold is the size from which it pays):

@@ -206,9 +206,11 @@ def test_spheres_follow_the_bounds_and_the_ranges(mc, O, H, pctx, kitten, bunny)
         compare(mc, pctx, O.cull_scene(O.View(g), t, ml, ranges=(off, cnt), tests=3), n)
 
 
-def test_a_precull_that_removes_nothing_backs_off(mc, O, H, kitten, monkeypatch):
+def test_a_precull_that_removes_nothing_backs_off(mc, O, H, kitten, monkeypatch, forced):
     """The default context drops the pre-cull for a while after one that kept more than 90 % of the units, and
     tries again later; the results never change."""
+    if not forced.adaptive:
+        pytest.skip("the run's switches take the back-off away")
     monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
     ml = kitten["meshlets"]
     n = 64

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The measured evidence of one round, produced on the GPU box: tools/profile_round.sh <tag> [lines|traces|pmc ...]
+# The measured evidence of one round, produced on the GPU box: tools/profile_round.sh <tag> [lines|traces|pmc|insts ...]
 # Writes <tag>_bench_<workload>.json (bench lines), <tag>_bench_<workload>_kernel_stats.csv and _summary.json
 # (rocprofv3 kernel trace of the same command, and for the headline the FETCH_SIZE / WRITE_SIZE passes) under
 # gpurun_out/<tag>/; what is to be kept is then copied to profiles/.  Every GPU step has its own time limit and
@@ -7,7 +7,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$1; shift
-WHAT=${*:-lines traces pmc}
+WHAT=${*:-lines traces pmc insts}
 O=$R/gpurun_out/$T
 mkdir -p $O
 line() {
@@ -33,6 +33,14 @@ pmc() {
     echo "counted $c for $name"
   done
   python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --fetch /tmp/pmc_${name}_FETCH_SIZE --write /tmp/pmc_${name}_WRITE_SIZE --out-dir $O > /dev/null || exit 1
+}
+insts() {
+  local name=$1; shift
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/pmc_${name}_insts
+  timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-include-regex "mcull" --output-format csv -d /tmp/pmc_${name}_insts -o p -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; exit 1; }
+  echo "counted instructions for $name"
+  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --insts /tmp/pmc_${name}_insts --out-dir $O > /dev/null || exit 1
 }
 for w in $WHAT; do
   case $w in
@@ -62,6 +70,10 @@ for w in $WHAT; do
       ;;
     pmc)
       pmc config4 || exit 1
+      ;;
+    insts)  # after `traces` in the same call: the summary is rewritten with the durations beside the counters
+      insts config3 --workload config3 || exit 1
+      insts config5 --workload config5 || exit 1
       ;;
   esac
 done

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--insts", help="a --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE pass of the same command")
     ap.add_argument("--prefix", default="mcull::")
     ap.add_argument("--out-dir", default=os.path.join(ROOT, "profiles"))
     args = ap.parse_args()
@@ -77,6 +78,31 @@ def main():
             kib = sum(v) / len(v)
             summary.setdefault(k, {})["%s_size_kib_raw" % kind] = round(kib, 1)
             summary[k]["%s_bytes_corrected" % kind] = int(kib * 1024 * factor)
+    if args.insts:
+        # wave-instructions per launch, and the clock while the kernel ran: GRBM_GUI_ACTIVE sums the busy cycles of the 8
+        # XCDs, the timestamps of the same dispatch give its duration in that (serialised) pass
+        acc = {}
+        f = sorted(glob.glob(os.path.join(args.insts, "**", "*counter_collection.csv"), recursive=True))[-1]
+        for r in csv.DictReader(open(f)):
+            if args.prefix not in r["Kernel_Name"]:
+                continue
+            k = acc.setdefault(short(r["Kernel_Name"]), {"launches": set(), "ns": {}})
+            k["launches"].add(r["Dispatch_Id"])
+            k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            k["ns"][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for name, k in acc.items():
+            n = len(k["launches"])
+            row = summary.setdefault(name, {})
+            row["waves_per_launch"] = int(k.get("SQ_WAVES", 0.0) / n)
+            row["valu_insts_per_launch"] = int(k.get("SQ_INSTS_VALU", 0.0) / n)
+            row["salu_insts_per_launch"] = int(k.get("SQ_INSTS_SALU", 0.0) / n)
+            if row["waves_per_launch"]:
+                row["valu_per_wave"] = round(row["valu_insts_per_launch"] / row["waves_per_launch"], 1)
+                row["salu_per_wave"] = round(row["salu_insts_per_launch"] / row["waves_per_launch"], 1)
+            ns = sum(k["ns"].values())
+            if ns and k.get("GRBM_GUI_ACTIVE"):
+                row["counter_pass_avg_us"] = round(ns / n / 1e3, 3)
+                row["clock_mhz"] = round(k["GRBM_GUI_ACTIVE"] / 8.0 / ns * 1e3, 1)
     with open(os.path.join(out_dir, "%s_summary.json" % args.tag), "w") as o:
         json.dump(summary, o, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
