@@ -260,3 +260,58 @@ def test_a_group_level_that_removes_nothing_backs_off(mc, O, H, monkeypatch, for
             else:
                 skipped += 1
         assert ran >= 1 and skipped >= 3, (ran, skipped)
+
+
+def test_window_tables_follow_the_pyramid_also_under_a_replayed_graph(mc, O, H, gctx, forced):
+    """The two levels prove occlusion from sliding-window minima that a cull derives from the pyramid when it finds them
+    out of date.  A rebuilt pyramid must never be culled against tables of the image before it: neither when the library
+    sees the rebuild (it makes new tables) nor when a captured cull is replayed after a rebuild it knows nothing of (the
+    build has cleared the word that says the tables are complete, and the replayed kernels do without them)."""
+    import torch
+
+    w, h = 1280, 720
+    per, n_inst = 2560, 120
+    cone, sphere = ribbon(H, per, seed=31)
+    t = transforms(H, n_inst, seed=17)
+    off, cnt = np.zeros(n_inst, dtype="<u4"), np.full(n_inst, per, dtype="<u4")
+    walls = np.full((h, w), 0.9, dtype="<f4")          # everything hidden
+    holes = walls.copy()
+    holes[:, w // 2:] = 0.0                            # ... except in the right half
+    discs = occluders(H, w, h, seed=9)
+    g = H.create_globals(eye=(38.0, 33.0, 28.0), width=w, height=h, flip_y=True, meshlet_count=per)
+    gctx.upload_bounds_soa(cone, sphere)
+    gctx.upload_transforms(t)
+    gctx.set_instance_ranges(None, None)
+    refs = {}
+    for name, depth in (("walls", walls), ("holes", holes), ("discs", discs)):
+        refs[name] = O.cull_scene(O.View(g, O.hiz_build(depth), w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=7)
+    assert refs["walls"].total == 0 < refs["holes"].total
+    # rebuilds the library sees: every cull is checked against the image its pyramid was last built from
+    dropped = {}
+    for name, depth in (("walls", walls), ("holes", holes), ("discs", discs), ("walls", walls), ("discs", discs)):
+        gctx.hiz_build(depth, view=0)
+        for _ in range(2):  # the second cull finds the tables made by the first
+            gctx.cull(g, tests=7, write_mask=True)
+            compare(mc, gctx, refs[name], n_inst)
+        dropped[name] = gctx.precull_stats()[0]
+    assert dropped["walls"] > dropped["holes"], "a wall hides more instances than half a wall"
+    # a captured cull (view constants and depth image in device memory) replayed after rebuilds outside the graph
+    stream = torch.cuda.Stream()
+    with mc.Context(0, stream=stream.cuda_stream) as c, torch.cuda.stream(stream):
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        g_dev = torch.from_numpy(np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1).view("u1").reshape(-1).copy()).to("cuda:0")
+        d_dev = {name: torch.from_numpy(depth).to("cuda:0") for name, depth in (("walls", walls), ("holes", holes), ("discs", discs))}
+        torch.cuda.synchronize()
+        c.hiz_build(d_dev["walls"].data_ptr(), view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+        for _ in range(2):  # buffers allocated and tables current before the capture
+            c.cull_device_globals(g_dev.data_ptr(), per, tests=7, write_mask=True)
+        compare(mc, c, refs["walls"], n_inst)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            c.cull_device_globals(g_dev.data_ptr(), per, tests=7, write_mask=True)
+        for name in ("holes", "discs", "walls", "holes"):
+            c.hiz_build(d_dev[name].data_ptr(), view=0, width=w, height=h, mem=mc.MEM_DEVICE)
+            graph.replay()
+            stream.synchronize()
+            compare(mc, c, refs[name], n_inst)
