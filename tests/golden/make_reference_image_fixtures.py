@@ -15,6 +15,11 @@ Writes tests/golden/reference_screenshots.npz:
   flat_yx, flat_rgb  position and colour of every pixel of the meshlet capture whose 5x5
                      neighbourhood has one single colour other than the clear colour (the interior
                      of a meshlet's footprint), i.e. pixels whose colour names one meshlet index
+  shade_yx, shade_rgb  position and colour of every second pixel of the shaded capture that lies well inside the
+                     kittens (5x5 erosion of the foreground) and whose 3x3 neighbourhood varies by at most 4 levels per
+                     channel: places where the interpolated normal, which is what the fragment shader writes
+                     (shader.frag:12), changes slowly, so that the colour does not depend on how a rasteriser snaps
+                     sub-pixel positions
 Only pixel data derived from the images is stored; nothing of the reference's source.
 """
 import os
@@ -43,11 +48,17 @@ def main():
     flat[:2, :] = False  # the capture's top rows are window border
     yx = np.argwhere(flat).astype(np.uint16)
     rgb = painted[flat].astype(np.uint8)
+    smooth = ndi.binary_erosion(foreground, np.ones((5, 5), dtype=bool))
+    for c in range(3):
+        smooth &= (ndi.maximum_filter(shaded[..., c], size=3) - ndi.minimum_filter(shaded[..., c], size=3)) <= 4
+    smooth[:2, :] = False
+    shade_yx = np.argwhere(smooth)[::2].astype(np.uint16)
+    shade_rgb = shaded[shade_yx[:, 0].astype(np.int64), shade_yx[:, 1].astype(np.int64)].astype(np.uint8)
     out = os.path.join(HERE, "reference_screenshots.npz")
     np.savez_compressed(out, size=np.array(shaded.shape[:2], dtype=np.uint16), foreground_bits=np.packbits(foreground),
-                        flat_yx=yx, flat_rgb=rgb)
-    print("foreground %.4f, flat pixels %d, distinct colours %d -> %s (%d bytes)"
-          % (foreground.mean(), len(yx), len(np.unique(rgb, axis=0)), out, os.path.getsize(out)))
+                        flat_yx=yx, flat_rgb=rgb, shade_yx=shade_yx, shade_rgb=shade_rgb)
+    print("foreground %.4f, flat pixels %d, distinct colours %d, shaded pixels %d -> %s (%d bytes)"
+          % (foreground.mean(), len(yx), len(np.unique(rgb, axis=0)), len(shade_yx), out, os.path.getsize(out)))
 
 
 if __name__ == "__main__":

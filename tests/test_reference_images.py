@@ -9,6 +9,9 @@ comparing pins, against the reference itself and not only against a restatement 
   * transforms, camera, projection and viewport conventions: the silhouette;
   * the OBJ loader, the vertex dedup, the triangle reorderer and the meshlet builder: which meshlet
     index covers which pixel (any difference in the partition or in the numbering recolours it).
+  * the vertex normals as the loader packs them into bytes (Engine.cpp:265-268: (n/2 + 1/2) * 255, truncated) and the
+    vertex each one belongs to: the first capture's colour IS the interpolated normal (shader.mesh:78-79 decodes the
+    bytes, shader.frag:12 writes (N + 1) / 2 to an sRGB target).
 The captures are 796x599 (the window's client area as grabbed), aligned with the top-left of the
 800x600 image; edges are compared with a 2-pixel tolerance.
 """
@@ -27,7 +30,8 @@ def shots():
     z = np.load(os.path.join(GOLDEN, "reference_screenshots.npz"))
     h, w = (int(x) for x in z["size"])
     fg = np.unpackbits(z["foreground_bits"])[: h * w].reshape(h, w).astype(bool)
-    return dict(h=h, w=w, foreground=fg, flat_yx=z["flat_yx"].astype(np.int64), flat_rgb=z["flat_rgb"].astype(np.int64))
+    return dict(h=h, w=w, foreground=fg, flat_yx=z["flat_yx"].astype(np.int64), flat_rgb=z["flat_rgb"].astype(np.int64),
+                shade_yx=z["shade_yx"].astype(np.int64), shade_rgb=z["shade_rgb"].astype(np.float64))
 
 
 def all_pairs(O, n_inst, n_meshlets, meshlet=None):
@@ -117,6 +121,106 @@ def test_oracle_culled_frame_still_shows_the_reference_image(O, kitten, config1,
             d = O.rasterize_depth(vt, md, ml, t, part, g, W, H)
             ids[(d > 0) & (d == depth)] = m
     check_meshlet_colours(ids, shots, len(ml))
+
+
+def winners(O, kitten, config1):
+    """Per pixel of the whole scene: depth, and the instance and the meshlet that own the nearest surface."""
+    g, t = config1["globals"], config1["transforms"]
+    ml, md, vt = kitten["meshlets"], kitten["meshlet_data"], kitten["vertices"]
+    depth = O.rasterize_depth(vt, md, ml, t, all_pairs(O, len(t), len(ml)), g, W, H)
+    inst = np.full((H, W), -1, dtype=np.int64)
+    mid = np.full((H, W), -1, dtype=np.int64)
+    one = np.zeros(len(ml), dtype=O.VISIBLE)
+    one["meshletID"] = np.arange(len(ml))
+    for i in range(len(t)):
+        one["drawID"] = i
+        d = O.rasterize_depth(vt, md, ml, t, one, g, W, H)
+        inst[(d > 0) & (d == depth)] = i
+    for m in range(len(ml)):
+        d = O.rasterize_depth(vt, md, ml, t, all_pairs(O, len(t), len(ml), meshlet=m), g, W, H)
+        mid[(d > 0) & (d == depth)] = m
+    return depth, inst, mid
+
+
+def interpolated_normal_bytes(kitten, config1, inst, mid, ys, xs):
+    """The packed normal (three bytes, as real numbers) that a rasteriser hands the fragment shader at the centres of the
+    pixels (ys, xs): the front-facing triangle of the pixel's instance and meshlet that is nearest there (reverse Z),
+    its three vertex normals weighted perspective-correctly.  Float64 and a plain inside test: the pixels asked about lie
+    inside smooth regions, where neither the fill rule nor the last bit of an edge function matters."""
+    g, t = config1["globals"].reshape(-1)[0], config1["transforms"]
+    ml, md, vt = kitten["meshlets"], kitten["meshlet_data"], kitten["vertices"]
+    vp = np.array(g["proj"], dtype=np.float64).reshape(4, 4).T @ np.array(g["view"], dtype=np.float64).reshape(4, 4).T
+    pos = vt["pos"][:, :3].astype(np.float64)
+    nrm = vt["n"][:, :3].astype(np.float64)
+    out = np.full((len(ys), 3), np.nan)
+    keys = inst[ys, xs] * len(ml) + mid[ys, xs]
+    order = np.argsort(keys, kind="stable")
+    uk, starts = np.unique(keys[order], return_index=True)
+    ends = list(starts[1:]) + [len(order)]
+    for k, b, e in zip(uk, starts, ends):
+        if k < 0:
+            continue
+        sel = order[b:e]
+        i, m = divmod(int(k), len(ml))
+        mvp = vp @ np.array(t[i]["model"], dtype=np.float64).reshape(4, 4).T
+        first, nv, nt = int(ml[m]["dataOffset"]), int(ml[m]["vertexCount"]), int(ml[m]["triangleCount"])
+        verts = md[first:first + nv]
+        tri = md[first + nv:first + nv + (nt * 3 + 3) // 4].view(np.uint8)[:nt * 3].reshape(-1, 3)
+        clip = np.concatenate([pos[verts], np.ones((nv, 1))], axis=1) @ mvp.T
+        w = clip[:, 3]
+        sx, sy, sz = (clip[:, 0] / w * 0.5 + 0.5) * W, (clip[:, 1] / w * 0.5 + 0.5) * H, clip[:, 2] / w
+        a, b_, c = tri[:, 0], tri[:, 1], tri[:, 2]
+        area = (sx[b_] - sx[a]) * (sy[c] - sy[a]) - (sx[c] - sx[a]) * (sy[b_] - sy[a])
+        px, py = xs[sel] + 0.5, ys[sel] + 0.5
+
+        def edge(p, q):
+            return (sx[q] - sx[p])[None, :] * (py[:, None] - sy[p][None, :]) - (sy[q] - sy[p])[None, :] * (px[:, None] - sx[p][None, :])
+
+        w0, w1, w2 = edge(b_, c), edge(c, a), edge(a, b_)
+        inside = (w0 <= 0) & (w1 <= 0) & (w2 <= 0) & ((area < 0) & (w[a] > 0) & (w[b_] > 0) & (w[c] > 0))[None, :]
+        z = np.where(inside, (w0 * sz[a][None, :] + w1 * sz[b_][None, :] + w2 * sz[c][None, :]) / area[None, :], -1.0)
+        best = z.argmax(axis=1)
+        rows = np.arange(len(sel))
+        hit = inside[rows, best]
+        q0, q1, q2 = (w0[rows, best] / w[a[best]], w1[rows, best] / w[b_[best]], w2[rows, best] / w[c[best]])  # (area cancels)
+        n = (q0[:, None] * nrm[verts[a[best]]] + q1[:, None] * nrm[verts[b_[best]]] + q2[:, None] * nrm[verts[c[best]]]) / (q0 + q1 + q2)[:, None]
+        out[sel[hit]] = n[hit]
+    return out
+
+
+def srgb_bytes(linear):
+    x = np.clip(linear, 0.0, 1.0)
+    return np.round(255.0 * np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055))
+
+
+def test_packed_normals_reproduce_the_colours_of_the_shaded_screenshot(O, kitten, config1, shots):
+    """shader.mesh:78-79 decodes the vertex's normal bytes to b / 255 * 2 - 1, the rasteriser interpolates, shader.frag:12
+    writes (N + 1) / 2 = b / 255 to an sRGB target: a pixel of the first capture shows the interpolated normal BYTES.
+    Computed here from this build's vertex buffer (the loader's bytes, its vertex dedup and order, the meshlets' local
+    indices) they must give the capture's colours, and give them best as they are: bytes half a unit or a unit higher or
+    lower - what rounding instead of Engine.cpp:265-268's truncation, or another scaling, would produce - fit worse."""
+    _, inst, mid = winners(O, kitten, config1)
+    ys, xs = shots["shade_yx"][:, 0], shots["shade_yx"][:, 1]
+    assert ((inst[ys, xs] >= 0) & (mid[ys, xs] >= 0)).mean() > 0.999
+    n = interpolated_normal_bytes(kitten, config1, inst, mid, ys, xs)
+    got = ~np.isnan(n[:, 0])
+    assert got.mean() > 0.999
+    captured = shots["shade_rgb"][got]
+    error = {}
+    for shift in (-1.0, -0.5, 0.0, 0.5, 1.0):
+        diff = np.abs(srgb_bytes((n[got] + shift) / 255.0) - captured)
+        error[shift] = diff.mean()
+        if shift == 0.0:
+            assert (diff.max(axis=1) <= 2).mean() > 0.99, (diff.max(axis=1) <= 2).mean()
+            assert (diff.max(axis=1) <= 4).mean() > 0.999
+    assert error[0.0] < 0.65, error
+    assert error[0.0] + 0.01 < error[0.5] < error[1.0] and error[0.0] + 0.05 < error[-0.5] < error[-1.0], error
+    # and the statement is about the normals: the same bytes from the wrong vertices (the vertex buffer rotated by one) do not fit
+    wrong = dict(kitten)
+    wrong["vertices"] = kitten["vertices"].copy()
+    wrong["vertices"]["n"] = np.roll(kitten["vertices"]["n"], 1, axis=0)
+    m = interpolated_normal_bytes(wrong, config1, inst, mid, ys, xs)
+    assert np.abs(srgb_bytes(m[got] / 255.0) - captured).mean() > 3.0 * error[0.0]
 
 
 @pytest.mark.gpu
