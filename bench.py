@@ -833,7 +833,7 @@ def pmc_traffic(args, workload, n_inst, per):
         return None, None
     if args.no_precull or args.exact:
         return None, None
-    return pmc_summary_bytes("r02_bench_config4", ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel",
+    return pmc_summary_bytes("r03_bench_config4", ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel",
                                                    "emit_commands_kernel"))
 
 

@@ -45,11 +45,15 @@ insts() {
 for w in $WHAT; do
   case $w in
     lines)
+      # bench.py quotes the counter passes of the committed summaries: after `traces pmc insts` of the same call they are these
+      cp $O/${T}_bench_config[345]_summary.json $R/profiles/ 2>/dev/null
       line config4 || exit 1
       line config4_hiz_flipped --hiz || exit 1
       line config4_hiz_unflipped --hiz --unflipped || exit 1
       line config4_no_precull --no-precull || exit 1
       line config4_force_dist --force-dist --no-strong-leg || exit 1
+      line config4_shard --force-dist --no-strong-leg --instances 97656 || exit 1
+      line config4_moving_camera --moving-camera || exit 1
       line config3 --workload config3 --steps 20 --warmup 3 || exit 1
       line config3_random --workload config3 --c3-mesh random --steps 20 --warmup 3 || exit 1
       line config5 --workload config5 --steps 20 --warmup 3 || exit 1
