@@ -43,11 +43,13 @@ calls = {
  "mcull_scene_info": (None, None), "mcull_scene_load": (None, None, None, None, None, None, None, None),
  "mcull_scene_save": (None, None, 0, None, 0, None, 0, None, 0, None, None, 0), "mcull_mesh_load_obj": (None, None),
  "mcull_mesh_from_arrays": (None, 0, None, 0, None, 0, None, 0, None),
+ "mcull_rccl_unique_id": (None,), "mcull_rccl_comm_create": (None, 1, 0, 0, None),
+ "mcull_allgather_commands": (None, None, None, None, 1, 1, None, None),
 }
 
 # entry points without a pointer that could be null, or that accept null by contract
 exempt = {"mcull_last_error", "mcull_status_string", "mcull_version", "mcull_hiz_level_count", "mcull_hiz_layout",
-          "mcull_mesh_destroy", "mcull_group_last_error"}
+          "mcull_mesh_destroy", "mcull_group_last_error", "mcull_collective_last_error", "mcull_rccl_comm_destroy"}
 missing = set(mc.ABI_SYMBOLS) - set(calls) - exempt
 assert not missing, missing
 for name, args in calls.items():
@@ -57,6 +59,7 @@ for name, args in calls.items():
     assert ok, (name, r)
 assert lib.mcull_last_error(None) == b"null context" and lib.mcull_group_last_error(None) == b"null group"
 lib.mcull_mesh_destroy(None)
+assert lib.mcull_rccl_comm_destroy(None) == 0 and lib.mcull_collective_last_error() is not None
 print("probed", len(calls))
 '''
 
