@@ -524,10 +524,9 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         if workload == "config5" and not args.separate_views:
             # the pyramid of every view is rebuilt from its depth each step, then ONE pass over the
             # bounds culls all views (each into its own context-owned list / commands / count)
-            for v in range(n_views):
-                ctx.hiz_build(depth.data_ptr(), view=v, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
-                if record:
-                    ms += ctx.last_kernel_ms()
+            ctx.hiz_build_views([depth.data_ptr()] * n_views, width=hiz_size[0], height=hiz_size[1], mem=mc.MEM_DEVICE)
+            if record:
+                ms += ctx.last_kernel_ms()
             ctx.cull_views(views, view_params[b])
             if record:
                 ms += ctx.last_kernel_ms()
@@ -700,7 +699,7 @@ def run_cull(env, workload):
             w, h = r["hiz_size"]
             algo += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
             algo_all += n_views * (4.0 * w * h + 4.0 * mc.hiz_layout(w, h)[4])
-            kernels = ("8 x (hiz_rows_kernel + hiz_tile_kernel) + cull_mask_views_kernel + 8 x (scan_tiles_kernel + compact_kernel + emit_commands_kernel)"
+            kernels = ("hiz_rows_views_kernel + hiz_tile_views_kernel (8 pyramids) + classify_views_kernel + cull_mask_views_kernel + scan_tiles_views_kernel + compact_views_kernel + emit_commands_views_kernel"
                        if not args.separate_views else
                        "8 x (hiz_rows_kernel + hiz_tile_kernel + cull_mask_kernel + scan_tiles_kernel + compact_kernel + emit_commands_kernel)")
             name = ("config 5: %d instances x %d unique meshlets against 8 views, one 8192^2 Hi-Z pyramid per view rebuilt "

@@ -167,6 +167,12 @@ public:
     void buildHiZPyramid(const float *depth, uint32_t width, uint32_t height, uint32_t view = 0, bool on_device = false) {
         MCULL_CHECK(ctx_, mcull_hiz_build(ctx_, view, depth, width, height, on_device ? MCULL_MEM_DEVICE : MCULL_MEM_HOST));
     }
+    // the pyramids of several views of one size at once (slots 0 .. depth.size() - 1), images in device memory
+    void buildHiZPyramids(const std::vector<const float *> &depth, uint32_t width, uint32_t height) {
+        std::vector<uint32_t> views(depth.size());
+        for (size_t i = 0; i < views.size(); i++) views[i] = (uint32_t)i;
+        MCULL_CHECK(ctx_, mcull_hiz_build_views(ctx_, (uint32_t)depth.size(), views.data(), depth.data(), width, height, MCULL_MEM_DEVICE));
+    }
     // the task shader over every (instance, meshlet) pair + global compaction
     mcull_cull_result cull(const Globals &globals, const mcull_cull_params *params = nullptr) {
         mcull_cull_result r{};

@@ -22,7 +22,7 @@ calls = {
  "mcull_destroy": (None,), "mcull_synchronize": (None,), "mcull_upload_meshlets": (None, P, 1, 0),
  "mcull_upload_bounds_soa": (None, P, P, 1, 0, 0), "mcull_upload_geometry": (None, P, 1, P, 1, 0),
  "mcull_compute_bounds": (None,), "mcull_download_meshlets": (None, P, 1), "mcull_upload_transforms": (None, P, 1, 0),
- "mcull_set_instance_ranges": (None, P, P, 1), "mcull_hiz_build": (None, 0, P, 4, 4, 0),
+ "mcull_set_instance_ranges": (None, P, P, 1), "mcull_hiz_build": (None, 0, P, 4, 4, 0), "mcull_hiz_build_views": (None, 1, P, P, 4, 4, 0),
  "mcull_hiz_pyramid": (None, 0, None, None), "mcull_hiz_download_level": (None, 0, 0, P),
  "mcull_cull": (None, P, None, None), "mcull_cull_static": (None, P, None, None), "mcull_cull_views": (None, 1, P, None, None), "mcull_select_result": (None, 0),
  "mcull_cull_device_globals": (None, P, 1, None, None), "mcull_cull_views_device_globals": (None, 1, P, 1, None, None),

@@ -166,6 +166,47 @@ def test_hiz_pyramid_bit_exact(mc, O, ctx, shape):
         assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "level %d differs" % k
 
 
+@pytest.mark.parametrize("shape,mem", [((2160, 3840), "device"), ((2306, 4100), "device"), ((2160, 3840), "host"), ((600, 800), "device"), ((5, 3), "host")])
+def test_pyramids_of_several_views_in_one_call(mc, O, H, shape, mem):
+    """mcull_hiz_build_views = one mcull_hiz_build per view: every texel of every level of every slot (one image holds
+    NaNs, infinities and -0), twice in a row, and a slot that is not named stays as it was.  Large images in device
+    memory take the batched launches; host images, small ones and odd widths the others."""
+    import torch
+
+    h, w = shape
+    rs = np.random.RandomState(h + w)
+    images = []
+    for k in range(3):
+        d = rs.uniform(0, 1, (h, w)).astype("<f4")
+        if k == 1 and h * w > 16:
+            d.flat[rs.randint(0, h * w, 6)] = [np.nan, -0.0, np.inf, -np.inf, 1e-40, np.nan]
+        images.append(d)
+    refs = [O.hiz_levels(O.hiz_build(d), w, h) for d in images]
+    slots = [5, 0, 3]
+    with mc.Context(0) as c:
+        other = rs.uniform(0, 1, (40, 60)).astype("<f4")
+        c.hiz_build(other, view=1)
+        for repeat in range(2):  # the second build finds every buffer in place (and the ticket words as the first left them)
+            if mem == "device":
+                dev = [torch.from_numpy(d).to("cuda:0") for d in images]
+                torch.cuda.synchronize()
+                c.hiz_build_views([t.data_ptr() for t in dev], views=slots, width=w, height=h, mem=mc.MEM_DEVICE)
+            else:
+                c.hiz_build_views(images, views=slots, mem=mc.MEM_HOST)
+            for slot, ref in zip(slots, refs):
+                got = c.hiz_download(view=slot)
+                assert len(got) == len(ref)
+                for k, (a, b) in enumerate(zip(got, ref)):
+                    assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "slot %d level %d differs" % (slot, k)
+        untouched = c.hiz_download(view=1)
+        for a, b in zip(untouched, O.hiz_levels(O.hiz_build(other), 60, 40)):
+            assert a.view("<u4").tobytes() == b.view("<u4").tobytes()
+        with pytest.raises(mc.McullError):
+            c.hiz_build_views(images[:2], views=[2, 2], mem=mc.MEM_HOST)  # one slot named twice
+        with pytest.raises(mc.McullError):
+            c.hiz_build_views(images[:1], views=[8], mem=mc.MEM_HOST)
+
+
 @pytest.mark.parametrize("shape", [(1080, 1920), (2160, 3840)])
 def test_hiz_rebuild_same_buffer_sees_no_stale_texels(mc, O, ctx, shape):
     """Rebuilding into the same pyramid with different depth must not pick up the previous build's

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "mcull_create", "mcull_destroy", "mcull_last_error", "mcull_status_string", "mcull_synchronize", "mcull_version",
     "mcull_upload_meshlets", "mcull_upload_bounds_soa", "mcull_upload_geometry", "mcull_compute_bounds",
     "mcull_download_meshlets", "mcull_upload_transforms", "mcull_set_instance_ranges", "mcull_hiz_level_count",
-    "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
+    "mcull_hiz_layout", "mcull_hiz_build", "mcull_hiz_build_views", "mcull_hiz_pyramid", "mcull_hiz_download_level", "mcull_cull",
     "mcull_rebase_commands", "mcull_task_payload_count", "mcull_emit_task_payloads", "mcull_download_count",
     "mcull_download_list", "mcull_download_commands", "mcull_download_mask", "mcull_enable_timing",
     "mcull_last_kernel_ms", "mcull_scene_save", "mcull_scene_info", "mcull_scene_load", "mcull_scene_upload", "mcull_depth_rasterize", "mcull_depth_buffer", "mcull_depth_download",
@@ -113,6 +113,7 @@ _sig("mcull_set_instance_ranges", _I, [_P, _P, _P, _U64])
 _sig("mcull_hiz_level_count", _U32, [_U32, _U32])
 _sig("mcull_hiz_layout", _U64, [_U32, _U32, C.POINTER(_U32), _P, _P, _P])
 _sig("mcull_hiz_build", _I, [_P, _U32, _P, _U32, _U32, _I])
+_sig("mcull_hiz_build_views", _I, [_P, _U32, _P, _P, _U32, _U32, _I])
 _sig("mcull_hiz_pyramid", _I, [_P, _U32, C.POINTER(_P), C.POINTER(_U64)])
 _sig("mcull_hiz_download_level", _I, [_P, _U32, _U32, _P])
 _sig("mcull_cull", _I, [_P, _P, C.POINTER(CullParams), C.POINTER(CullResult)])
@@ -560,6 +561,24 @@ class Context:
             self._chk(lib.mcull_hiz_build(self._h, view, depth, width, height, MEM_DEVICE))
         self._hiz_dims = getattr(self, "_hiz_dims", {})
         self._hiz_dims[view] = (width, height)
+
+    def hiz_build_views(self, depths, views=None, width=None, height=None, mem=MEM_DEVICE):
+        """The pyramids of several views of one size (mcull_hiz_build_views).  depths: device pointers (mem=MEM_DEVICE, with
+        width and height) or 2-D host arrays of one shape (mem=MEM_HOST); views: the slots, default 0 .. n - 1."""
+        n = len(depths)
+        slots = (_U32 * n)(*(range(n) if views is None else views))
+        keep = []
+        if mem == MEM_HOST:
+            keep = [np.ascontiguousarray(d, dtype="<f4") for d in depths]
+            height, width = keep[0].shape
+            assert all(k.shape == keep[0].shape for k in keep)
+            ptrs = (_P * n)(*[k.ctypes.data for k in keep])
+        else:
+            ptrs = (_P * n)(*[int(d) for d in depths])
+        self._chk(lib.mcull_hiz_build_views(self._h, n, slots, ptrs, width, height, mem))
+        self._hiz_dims = getattr(self, "_hiz_dims", {})
+        for v in slots:
+            self._hiz_dims[int(v)] = (width, height)
 
     def hiz_pyramid_ptr(self, view=0):
         p, n = _P(), _U64()

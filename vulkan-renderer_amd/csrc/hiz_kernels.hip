@@ -19,6 +19,8 @@
 // of the cull needs to know.  `nan_seen` points at two words: the kernels that read the image set word 1 when they
 // meet a NaN, and the LAST launch of every build moves it to word 0 - what the culls read - and clears it
 // (publish_nan_word), so word 0 always describes the image the pyramid was last built from.
+#include <cstring>
+
 #include "mcull_internal.h"
 
 namespace mcull {
@@ -123,7 +125,7 @@ __device__ __forceinline__ float wave_level(float v, uint32_t K, uint32_t levels
 // of the pyramid that is already in place (`depth` points at it, `tbl` at that level's table entries
 // and `levels` counts from it), just written by the previous launch, so it is read with plain loads.
 template <bool VEC, bool SINGLE_PASS, bool COPY>
-__global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
+__device__ __forceinline__ void hiz_tile_body(const float *__restrict__ depth, uint32_t w, uint32_t h,
                                                           float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
                                                           uint32_t levels, uint32_t *__restrict__ counter,
                                                           uint32_t *__restrict__ nan_seen, float *__restrict__ strips,
@@ -311,6 +313,34 @@ __global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restric
     }
 }
 
+template <bool VEC, bool SINGLE_PASS, bool COPY>
+__global__ __launch_bounds__(kBlock) void hiz_tile_kernel(const float *__restrict__ depth, uint32_t w, uint32_t h,
+                                                          float *__restrict__ pyr, const uint32_t *__restrict__ tbl,
+                                                          uint32_t levels, uint32_t *__restrict__ counter,
+                                                          uint32_t *__restrict__ nan_seen, float *__restrict__ strips,
+                                                          uint32_t strips_w, uint32_t strips_h) {
+    hiz_tile_body<VEC, SINGLE_PASS, COPY>(depth, w, h, pyr, tbl, levels, counter, nan_seen, strips, strips_w, strips_h);
+}
+
+// Several pyramids of one size in one launch each (launch_hiz_views): blockIdx.z picks the view's buffers.  Built one after
+// another, the small second launches of eight 8192^2 pyramids run one by one on a nearly idle chip.
+struct HizViews {
+    const float *depth[MCULL_MAX_VIEWS];
+    float *pyramid[MCULL_MAX_VIEWS];
+    const uint32_t *table[MCULL_MAX_VIEWS];
+    uint32_t *counter[MCULL_MAX_VIEWS];
+    uint32_t *nan_seen[MCULL_MAX_VIEWS];
+    float *strips[MCULL_MAX_VIEWS];
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void hiz_tile_views_kernel(HizViews b, size_t source_offset, uint32_t table_shift, uint32_t w,
+                                                                uint32_t h, uint32_t levels, uint32_t strips_w, uint32_t strips_h) {
+    const uint32_t v = blockIdx.z;
+    hiz_tile_body<VEC, true, false>(b.pyramid[v] + source_offset, w, h, b.pyramid[v], b.table[v] + table_shift, levels, b.counter[v],
+                                    b.nan_seen[v], b.strips[v], strips_w, strips_h);
+}
+
 constexpr uint32_t kRowsPerWave = 8;
 constexpr uint64_t kStreamMinTexels = 6ull << 20;
 // Eight rows x 4 texels of one lane: levels 0-3 stored, the level-3 texel returned (both lanes of a pair hold it).
@@ -427,6 +457,16 @@ __global__ __launch_bounds__(kBlock) void hiz_rows_kernel(const float *__restric
     const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
     if (y0 >= h) return;  // the whole wave lies below the image
     hiz_rows8<VEC>(depth, w, h, pyr, tbl, x0, y0, lane, nan_seen, strips, strips_w);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void hiz_rows_views_kernel(HizViews b, uint32_t w, uint32_t h, uint32_t strips_w) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t x0 = blockIdx.x * 256u + 4u * lane;
+    const uint32_t y0 = (blockIdx.y * (kBlock / 64u) + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (y0 >= h) return;
+    const uint32_t v = blockIdx.z;
+    hiz_rows8<VEC>(b.depth[v], w, h, b.pyramid[v], b.table[v], x0, y0, lane, b.nan_seen[v], b.strips[v], strips_w);
 }
 
 template <bool COPY>
@@ -554,6 +594,46 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
     for (uint32_t i = 0; i < base; i++) off += (size_t)max(1u, w >> i) * max(1u, h >> i);
     return launch_tiles<false>(pyramid + off, w >> base, h >> base, pyramid, levels - base, level_table + base, counter, true, nan_seen,
                                strips, (w + 63u) / 64u, (h + 7u) / 8u, st);
+}
+
+// n pyramids of one size, the streaming scheme with both launches batched over the views.  False: not applicable (another
+// scheme for this size, or buffers that the vector forms cannot take) - the caller builds them one by one.
+bool hiz_views_batchable(uint32_t w, uint32_t h, uint32_t levels, int mode) {
+    // ... and the second launch must be the form that finishes the pyramid inside itself (launch_tiles)
+    return hiz_writes_strips(w, h, mode) && levels > 3u + 7u && (w >> 3) <= kMaxSinglePass && (h >> 3) <= kMaxSinglePass;
+}
+
+hipError_t launch_hiz_views(uint32_t n, const float *const *depth, uint32_t w, uint32_t h, float *const *pyramid, uint32_t levels,
+                            uint32_t *const *level_table, uint32_t *const *counter, float *const *strips, hipStream_t st) {
+    constexpr uint32_t base = 3;
+    HizViews b;
+    std::memset(&b, 0, sizeof b);
+    bool vec = (w % 4u) == 0u;
+    for (uint32_t i = 0; i < n; i++) {
+        b.depth[i] = depth[i];
+        b.pyramid[i] = pyramid[i];
+        b.table[i] = level_table[i];
+        b.counter[i] = counter[i];
+        b.nan_seen[i] = level_table[i] + kHizNanWord;
+        b.strips[i] = strips[i];
+        vec = vec && (reinterpret_cast<uintptr_t>(depth[i]) & 15u) == 0u && (reinterpret_cast<uintptr_t>(pyramid[i]) & 15u) == 0u;
+    }
+    const dim3 grid((w + 255u) / 256u, (h + 4u * kRowsPerWave - 1u) / (4u * kRowsPerWave), n);
+    if (vec) hipLaunchKernelGGL((hiz_rows_views_kernel<true>), grid, dim3(kBlock), 0, st, b, w, h, (w + 63u) / 64u);
+    else hipLaunchKernelGGL((hiz_rows_views_kernel<false>), grid, dim3(kBlock), 0, st, b, w, h, (w + 63u) / 64u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    for (uint32_t i = 0; i < base; i++) off += (size_t)max(1u, w >> i) * max(1u, h >> i);
+    const uint32_t w3 = w >> base, h3 = h >> base;
+    const dim3 tiles((w3 + kTile - 1) / kTile, (h3 + kTile - 1) / kTile, n);
+    // level 3 starts 16-byte aligned when the pyramid does and the three levels below it hold a multiple of four texels
+    const bool vec3 = (w3 % 4u) == 0u && vec && (off % 4u) == 0u;
+    if (vec3) hipLaunchKernelGGL((hiz_tile_views_kernel<true>), tiles, dim3(kBlock), 0, st, b, off, base, w3, h3, levels - base,
+                                 (w + 63u) / 64u, (h + 7u) / 8u);
+    else hipLaunchKernelGGL((hiz_tile_views_kernel<false>), tiles, dim3(kBlock), 0, st, b, off, base, w3, h3, levels - base,
+                            (w + 63u) / 64u, (h + 7u) / 8u);
+    return hipGetLastError();
 }
 
 }  // namespace mcull

@@ -671,13 +671,10 @@ uint64_t mcull_hiz_layout(uint32_t width, uint32_t height, uint32_t *levels, uin
     return total;
 }
 
-int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t width, uint32_t height, int mem) {
-    if (!c) return MCULL_E_INVALID;
-    if (view >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view slot %u out of range", view);
-    if (!depth || width == 0 || height == 0) return fail(c, MCULL_E_INVALID, "empty depth image");
-    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
-    if (level_count(width, height) > MCULL_MAX_HIZ_LEVELS) return fail(c, MCULL_E_INVALID, "depth image too large");
-    HIPCHK(c, hipSetDevice(c->device));
+namespace {
+
+// buffers and level table of view slot `view` for a width x height image (everything of a build but its launches)
+int hiz_prepare(mcull_ctx *c, uint32_t view, uint32_t width, uint32_t height) {
     HizSlot &s = c->hiz[view];
     uint32_t levels;
     const uint64_t total = mcull_hiz_layout(width, height, &levels, s.lw, s.lh, s.loff);
@@ -688,9 +685,9 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
         if ((rc = ensure(c, s.table, mcull::kHizTableWords * 4))) return rc;
         HIPCHK(c, hipMemsetAsync(s.table.p, 0, mcull::kHizTableWords * 4, c->stream));
     }
-    if (!c->hiz_counter.p) {  // ticket words: zero once; the kernel's last workgroup re-zeroes them
-        if ((rc = ensure(c, c->hiz_counter, mcull::kHizCounterBytes))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->hiz_counter.p, 0, mcull::kHizCounterBytes, c->stream));
+    if (!c->hiz_counter.p) {  // ticket words, one set per view of a batched build: zero once; the kernels' last workgroups re-zero them
+        if ((rc = ensure(c, c->hiz_counter, MCULL_MAX_VIEWS * mcull::kHizCounterBytes))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->hiz_counter.p, 0, MCULL_MAX_VIEWS * mcull::kHizCounterBytes, c->stream));
     }
     if (!s.built || s.w != width || s.h != height) {
         uint32_t tbl[48];
@@ -698,26 +695,86 @@ int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t wi
         for (uint32_t i = 0; i < levels; i++) { tbl[i] = s.lw[i]; tbl[16 + i] = s.lh[i]; tbl[32 + i] = (uint32_t)s.loff[i]; }
         if ((rc = copy_in(c, s.table.p, tbl, sizeof tbl, MCULL_MEM_HOST))) return rc;
     }
+    s.has_strips = c->hiz_strips && mcull::hiz_writes_strips(width, height, c->hiz_mode);
+    if (s.has_strips && (rc = ensure(c, s.strips, mcull::hiz_strip_floats(width, height) * 4))) return rc;
+    s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
+    return MCULL_OK;
+}
+
+void hiz_built(HizSlot &s) {
+    s.built = true;
+    s.windows_current = false;
+    s.culls_since_build = 0;
+}
+
+}  // namespace
+
+int mcull_hiz_build(mcull_ctx *c, uint32_t view, const float *depth, uint32_t width, uint32_t height, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if (view >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view slot %u out of range", view);
+    if (!depth || width == 0 || height == 0) return fail(c, MCULL_E_INVALID, "empty depth image");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
+    if (level_count(width, height) > MCULL_MAX_HIZ_LEVELS) return fail(c, MCULL_E_INVALID, "depth image too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = hiz_prepare(c, view, width, height))) return rc;
+    HizSlot &s = c->hiz[view];
     const float *src = depth;
     if (mem == MCULL_MEM_HOST) {
         if ((rc = ensure(c, c->depth_staging, (size_t)width * height * 4))) return rc;
         if ((rc = copy_in(c, c->depth_staging.p, depth, (size_t)width * height * 4, MCULL_MEM_HOST))) return rc;
         src = (const float *)c->depth_staging.p;
     }
-    s.has_strips = c->hiz_strips && mcull::hiz_writes_strips(width, height, c->hiz_mode);
-    if (s.has_strips && (rc = ensure(c, s.strips, mcull::hiz_strip_floats(width, height) * 4))) return rc;
-    s.w = width; s.h = height; s.levels = levels; s.total_floats = total;
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, levels, (const uint32_t *)s.table.p,
+    HIPCHK(c, mcull::launch_hiz(src, width, height, (float *)s.pyramid.p, s.levels, (const uint32_t *)s.table.p,
                                 (uint32_t *)c->hiz_counter.p, (uint32_t *)s.table.p + mcull::kHizNanWord, (float *)s.strips.p,
                                 c->hiz_mode, c->stream));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->timed = true;
     }
-    s.built = true;
-    s.windows_current = false;
-    s.culls_since_build = 0;
+    hiz_built(s);
+    return MCULL_OK;
+}
+
+int mcull_hiz_build_views(mcull_ctx *c, uint32_t n_views, const uint32_t *views, const float *const *depth, uint32_t width,
+                          uint32_t height, int mem) {
+    if (!c) return MCULL_E_INVALID;
+    if (n_views == 0 || n_views > MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "n_views must be 1..%d", MCULL_MAX_VIEWS);
+    if (!views || !depth || width == 0 || height == 0) return fail(c, MCULL_E_INVALID, "empty depth images");
+    if (!mem_kind_ok(mem)) return fail(c, MCULL_E_INVALID, "mem must be MCULL_MEM_HOST or MCULL_MEM_DEVICE, not %d", mem);
+    if (level_count(width, height) > MCULL_MAX_HIZ_LEVELS) return fail(c, MCULL_E_INVALID, "depth image too large");
+    uint32_t seen = 0;
+    for (uint32_t i = 0; i < n_views; i++) {
+        if (views[i] >= MCULL_MAX_VIEWS) return fail(c, MCULL_E_INVALID, "view slot %u out of range", views[i]);
+        if (!depth[i]) return fail(c, MCULL_E_INVALID, "depth image %u is null", i);
+        if (seen & (1u << views[i])) return fail(c, MCULL_E_INVALID, "view slot %u named twice", views[i]);
+        seen |= 1u << views[i];
+    }
+    // images in host memory go through one staging buffer, and small images use schemes with launches of their own: one by one
+    if (mem == MCULL_MEM_HOST || n_views == 1 || !mcull::hiz_views_batchable(width, height, level_count(width, height), c->hiz_mode)) {
+        for (uint32_t i = 0; i < n_views; i++)
+            if (int rc = mcull_hiz_build(c, views[i], depth[i], width, height, mem)) return rc;
+        return MCULL_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    float *pyramid[MCULL_MAX_VIEWS], *strips[MCULL_MAX_VIEWS];
+    uint32_t *table[MCULL_MAX_VIEWS], *counter[MCULL_MAX_VIEWS];
+    for (uint32_t i = 0; i < n_views; i++) {
+        if (int rc = hiz_prepare(c, views[i], width, height)) return rc;
+        HizSlot &s = c->hiz[views[i]];
+        pyramid[i] = (float *)s.pyramid.p;
+        strips[i] = (float *)s.strips.p;
+        table[i] = (uint32_t *)s.table.p;
+        counter[i] = (uint32_t *)c->hiz_counter.p + (size_t)i * (mcull::kHizCounterBytes / 4);
+    }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mcull::launch_hiz_views(n_views, depth, width, height, pyramid, c->hiz[views[0]].levels, table, counter, strips, c->stream));
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+    }
+    for (uint32_t i = 0; i < n_views; i++) hiz_built(c->hiz[views[i]]);
     return MCULL_OK;
 }
 
