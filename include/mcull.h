@@ -285,7 +285,7 @@ int mcull_hiz_build(mcull_ctx *ctx, uint32_t view, const float *depth, uint32_t 
                     uint32_t height, int mem);
 /* The same for n_views depth images of ONE size (the shadow cascades or cameras of mcull_cull_views), image i into slot
  * views[i] (distinct slots): exactly what n_views calls of mcull_hiz_build give, but large images in device memory are built
- * with two launches in all instead of two per view (the reference would record buildHiZPyramid once per view,
+ * with three launches in all instead of two per view (the reference would record buildHiZPyramid once per view,
  * Engine.cpp:1834-1866; it has one view). */
 int mcull_hiz_build_views(mcull_ctx *ctx, uint32_t n_views, const uint32_t *views, const float *const *depth,
                           uint32_t width, uint32_t height, int mem);

@@ -337,8 +337,13 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void hiz_tile_views_kernel(HizViews b, size_t source_offset, uint32_t table_shift, uint32_t w,
                                                                 uint32_t h, uint32_t levels, uint32_t strips_w, uint32_t strips_h) {
     const uint32_t v = blockIdx.z;
-    hiz_tile_body<VEC, true, false>(b.pyramid[v] + source_offset, w, h, b.pyramid[v], b.table[v] + table_shift, levels, b.counter[v],
-                                    b.nan_seen[v], b.strips[v], strips_w, strips_h);
+    hiz_tile_body<VEC, false, false>(b.pyramid[v] + source_offset, w, h, b.pyramid[v], b.table[v] + table_shift, levels,
+                                           b.counter[v], b.nan_seen[v], b.strips[v], strips_w, strips_h);
+}
+
+// the levels the tiles leave (from k_begin of the shifted table on), one workgroup per view
+__global__ __launch_bounds__(kBlock) void hiz_top_views_kernel(HizViews b, uint32_t table_shift, uint32_t levels, uint32_t k_begin) {
+    reduce_levels_from_global(b.pyramid[blockIdx.x], b.table[blockIdx.x] + table_shift, k_begin, levels);
 }
 
 constexpr uint32_t kRowsPerWave = 8;
@@ -596,7 +601,7 @@ hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid
                                strips, (w + 63u) / 64u, (h + 7u) / 8u, st);
 }
 
-// n pyramids of one size, the streaming scheme with both launches batched over the views.  False: not applicable (another
+// n pyramids of one size, the streaming scheme with its launches batched over the views (three in all).  False: not applicable (another
 // scheme for this size, or buffers that the vector forms cannot take) - the caller builds them one by one.
 bool hiz_views_batchable(uint32_t w, uint32_t h, uint32_t levels, int mode) {
     // ... and the second launch must be the form that finishes the pyramid inside itself (launch_tiles)
@@ -629,10 +634,16 @@ hipError_t launch_hiz_views(uint32_t n, const float *const *depth, uint32_t w, u
     const dim3 tiles((w3 + kTile - 1) / kTile, (h3 + kTile - 1) / kTile, n);
     // level 3 starts 16-byte aligned when the pyramid does and the three levels below it hold a multiple of four texels
     const bool vec3 = (w3 % 4u) == 0u && vec && (off % 4u) == 0u;
+    // The tiles WITHOUT the ticket hand-over, then one workgroup per view for the levels they leave: with thousands of
+    // workgroups in one launch the tickets' releases (an L2 write-back each) queue up - eight 8192^2 pyramids finished
+    // inside the tile launch took 55.6 us for it, against 17.7 + 4.2 us this way.
     if (vec3) hipLaunchKernelGGL((hiz_tile_views_kernel<true>), tiles, dim3(kBlock), 0, st, b, off, base, w3, h3, levels - base,
                                  (w + 63u) / 64u, (h + 7u) / 8u);
     else hipLaunchKernelGGL((hiz_tile_views_kernel<false>), tiles, dim3(kBlock), 0, st, b, off, base, w3, h3, levels - base,
                             (w + 63u) / 64u, (h + 7u) / 8u);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hiz_top_views_kernel, dim3(n), dim3(kBlock), 0, st, b, base, levels - base, 7u);
     return hipGetLastError();
 }
 

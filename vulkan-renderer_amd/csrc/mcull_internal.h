@@ -219,7 +219,7 @@ bool hiz_writes_strips(uint32_t w, uint32_t h, int mode);
 size_t hiz_strip_floats(uint32_t w, uint32_t h);
 hipError_t launch_hiz(const float *depth, uint32_t w, uint32_t h, float *pyramid, uint32_t levels,
                       const uint32_t *level_table, uint32_t *counter, uint32_t *nan_seen, float *strips, int mode, hipStream_t st);
-// n pyramids of one size built with two launches in all (the streaming scheme, both launches batched over the views):
+// n pyramids of one size built with three launches in all (the streaming scheme, its launches batched over the views):
 // only where hiz_views_batchable says so; every view has its own kHizCounterBytes of ticket words.
 bool hiz_views_batchable(uint32_t w, uint32_t h, uint32_t levels, int mode);
 hipError_t launch_hiz_views(uint32_t n, const float *const *depth, uint32_t w, uint32_t h, float *const *pyramid, uint32_t levels,
