@@ -233,6 +233,7 @@ class Env:
         # the step's collective goes through the library (mcull_allgather_commands on a communicator of its own, made
         # from an id that torch.distributed carries to the ranks) unless --torch-collective asks for all_gather_into_tensor
         self.first_steps_ms = None
+        self.gather_mode = None
         self.native_comm = None
         self.collective = "torch.distributed all_gather_into_tensor + mcull_rebase_gathered_commands" if self.multi else None
         if self.multi and not args.rehearse_shared_gpu and not args.torch_collective:
@@ -513,12 +514,18 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
 
     native = [env.native_comm]  # set to None below if its first result is not what torch.distributed's gather gives
 
+    # shards whose cull is shorter than the host needs to enqueue two cross-stream edges (below 16 M pairs) gather on the
+    # cull's own stream; larger ones overlap the gather with the next cull
+    want_serial = args.serial_gather or (n_pairs * n_views < (16 << 20) and not args.overlap_gather)
+    serial_gather = bool(multi and native[0] is not None and want_serial and not gather_lists)
+    env.gather_mode = "on the cull's stream (serial)" if serial_gather else "on a side stream, overlapped with the next cull"
+
     host_s = [0.0, 0.0, 0]  # MCULL_BENCH_HOST_TIMES=1: host seconds spent enqueuing the culls / the gathers, steps
 
     def step(k, record=False, gather_lists=False):
         b = k & 1
         t0 = time.perf_counter()
-        if multi:
+        if multi and not serial_gather:
             main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
         ms = 0.0
         if workload == "config5" and not args.separate_views:
@@ -548,7 +555,11 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 if record:
                     ms += ctx.last_kernel_ms()
         t1 = time.perf_counter()
-        if multi:
+        if multi and serial_gather:
+            # small shards: the gather on the cull's own stream, behind it - no cross-stream edge to enqueue (two of them cost
+            # the host more than the collective), at the price of not overlapping the next cull
+            gathered[b] = env.mdist.gather_draw_list_native(native[0], main, cmds_packed[b], gather_buf[b], gather_out[b])
+        elif multi:
             # per-rank counts -> every rank's list offset -> rebased per-instance commands, gathered
             # into one global draw-list description; runs on a side stream beside the next cull
             ev_cull[b].record(main)
@@ -651,7 +662,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
                 precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances",
                              **({"group_level": {"dropped": grp_dropped, "tested": grp_tested}} if grp_tested else {})),
-                value=job_pairs * n_views / (elapsed / steps) / 1e9,
+                value=job_pairs * n_views / (elapsed / steps) / 1e9, gather_mode=env.gather_mode,
                 scene=(cone, sphere, xf, off, cnt))
 
 
@@ -689,9 +700,9 @@ def run_cull(env, workload):
         extra_cfg = {"meshlet_instances_per_gpu": n_pairs * n_views, "visible_fraction": round(visible / max(n_pairs, 1), 4),
                      **({"pairs_reaching_hiz": r["hiz_pairs"]} if r["hiz_pairs"] else {}),
                      "instance_precull": r["precull"],
-                     **({"collective": env.collective} if multi else {}),
+                     **({"collective": env.collective, "gather": env.gather_mode} if multi else {}),
                      **({"camera": "a different Globals every step: 0.2 degrees of orbit per step, 64-step cycle"} if args.moving_camera and workload == "config4" else {}),
-                     "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather, overlapped with the next cull" % shard_note)
+                     "parallelism": ("%s, one RCCL all-gather of commands + counts per step, rebased after the gather" % shard_note)
                      if multi else "single GPU"}
         if workload == "config5":
             if r["vis_views"]:
@@ -768,7 +779,7 @@ def run_cull(env, workload):
                                      "meshlet_instances_per_gpu": r2["n_pairs"] * r2["n_views"],
                                      "kernel_ms_single_call": round(r2["kernel_ms"], 4),
                                      "visible_fraction": round(r2["job_visible"] / max(r2["job_pairs"], 1), 4),
-                                     "with_list_gather": r2["with_lists"]}
+                                     "gather": r2["gather_mode"], "with_list_gather": r2["with_lists"]}
     if rank == 0:
         env.line(out)
 
@@ -1233,6 +1244,10 @@ def main():
     ap.add_argument("--separate-views", action="store_true", help="config5: one cull call per view instead of one fused pass")
     ap.add_argument("--ctx-outputs", action="store_true", help="experiment: context-owned list/commands instead of torch tensors")
     ap.add_argument("--copy-bounds", action="store_true", help="experiment: copy the bounds into library-owned memory instead of adopting")
+    ap.add_argument("--serial-gather", action="store_true",
+                    help="multi-rank cull workloads: the all-gather on the cull's own stream instead of overlapped on a side stream "
+                         "(the default below 16 M pairs per rank)")
+    ap.add_argument("--overlap-gather", action="store_true", help="... always on the side stream")
     ap.add_argument("--moving-camera", action="store_true",
                     help="config4: a different camera every step (a slow orbit), so that each cull's list differs from the last one's")
     ap.add_argument("--ramp-ms", type=float, default=60.0,
