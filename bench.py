@@ -525,7 +525,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     def step(k, record=False, gather_lists=False):
         b = k & 1
         t0 = time.perf_counter()
-        if multi and not serial_gather:
+        if multi and not (serial_gather and native[0] is not None):
             main.wait_event(ev_comm[b])  # the gather that last read buffer b has finished
         ms = 0.0
         if workload == "config5" and not args.separate_views:
@@ -555,7 +555,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 if record:
                     ms += ctx.last_kernel_ms()
         t1 = time.perf_counter()
-        if multi and serial_gather:
+        if multi and serial_gather and native[0] is not None:
             # small shards: the gather on the cull's own stream, behind it - no cross-stream edge to enqueue (two of them cost
             # the host more than the collective), at the price of not overlapping the next cull
             gathered[b] = env.mdist.gather_draw_list_native(native[0], main, cmds_packed[b], gather_buf[b], gather_out[b])
@@ -594,6 +594,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         if not bool(flag.item()):
             print("bench: mcull_allgather_commands disagreed with torch.distributed on rank %d; using torch.distributed" % rank, file=sys.stderr)
             native[0] = None
+            env.gather_mode = "on a side stream, overlapped with the next cull"
             env.collective = "torch.distributed all_gather_into_tensor + mcull_rebase_gathered_commands (the native collective's first result differed)"
         torch.cuda.synchronize()
     elapsed, dev_ms = env.timed(step, steps=steps, warmup=warmup)
