@@ -157,9 +157,16 @@ def create_native_comm(device, group=None):
     rank 0's unique id travels through the group (any backend), then every rank joins.  The communicator is what
     gather_draw_list_native hands to the library; torch.distributed is only the courier of 128 bytes."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [_pkg().rccl_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = _pkg().rccl_unique_id()
+        except Exception as e:  # noqa: BLE001 - told to every rank below, so that all of them give up together
+            box[0] = RuntimeError("rank 0 could not make an RCCL id: %s" % e)
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if isinstance(box[0], Exception):
+        raise box[0]
     return _pkg().RcclComm(box[0], world, rank, device)
 
 
