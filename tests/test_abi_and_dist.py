@@ -180,6 +180,40 @@ def _rank_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _native_comm_rank(rank, world, port, out_dir):
+    import importlib
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = importlib.import_module("vulkan-renderer_amd.dist")
+    try:
+        D.create_native_comm(0)
+        verdict = "made a communicator without a GPU"
+    except Exception as e:  # noqa: BLE001
+        verdict = "raised: %s" % e
+    with open(os.path.join(out_dir, "native_%d.txt" % rank), "w") as f:
+        f.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_communicator_failure_reaches_every_rank(tmp_path):
+    """Without a GPU no rank can join a communicator (and where RCCL itself is missing, rank 0 cannot even make the id:
+    every rank must then hear of it).  Each rank raises and goes on - to the barrier here, to the torch.distributed path in
+    the bench - instead of waiting in the broadcast for an id that never comes."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_native_comm_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        text = (tmp_path / ("native_%d.txt" % rank)).read_text()
+        assert text.startswith("raised:"), text
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_multi_rank_draw_list_gather_equals_single_rank(tmp_path, O, H, kitten, world):
     """world_size 2 and 4 over gloo: concatenated lists == the single-rank list, gathered commands ==
