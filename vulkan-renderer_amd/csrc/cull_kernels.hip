@@ -1966,11 +1966,27 @@ __device__ __forceinline__ void compact_body(
     }
     };
     if (LOOP) {
+        // The workgroup's tiles are blockIdx.x + k gridDim.x.  Their counters are looked at kBlock at a time, one per thread
+        // and all loads at once, and only the tiles that hold something are visited: asking one counter after the other put
+        // a memory round trip in front of every tile, empty or not (1 M instances of one mesh, 104 tiles per workgroup, nine
+        // in ten empty: 1.76 ms for a pass that writes 5.4 GB).
+        __shared__ uint64_t s_has[kWaves];
         const uint32_t n_tiles = (n_groups + kTileGroups - 1u) / kTileGroups;
-        for (uint32_t tile_idx = blockIdx.x; tile_idx < n_tiles; tile_idx += gridDim.x) {
-            if (tile_counts[tile_idx] == 0u) continue;  // uniform
-            do_tile(tile_idx, 0u);
-            __syncthreads();  // the staging arrays are rewritten by the next tile
+        for (uint64_t base = blockIdx.x; base < n_tiles; base += (uint64_t)gridDim.x * kBlock) {
+            const uint64_t mine = base + (uint64_t)threadIdx.x * gridDim.x;
+            const uint64_t has = __ballot(mine < n_tiles && tile_counts[mine] != 0u);
+            if (lane == 0) s_has[wave] = has;
+            __syncthreads();
+            for (uint32_t w = 0; w < (uint32_t)kWaves; w++) {
+                uint64_t m = s_has[w];  // uniform
+                while (m) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    do_tile((uint32_t)(base + (uint64_t)(w * 64u + bit) * gridDim.x), 0u);
+                    __syncthreads();  // the staging arrays are rewritten by the next tile
+                }
+            }
+            __syncthreads();  // s_has is rewritten by the next batch
         }
     } else {
         do_tile(blockIdx.x / split, blockIdx.x % split);
