@@ -2506,7 +2506,7 @@ hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets
 
 size_t work_list_bytes(uint64_t units, bool ranged) { return work_rec_offset_words(units) * 4 + (ranged ? units * 16 : 0); }
 
-// work = work_list_bytes(groups or instances) bytes whose first word the caller has zeroed; zero_mask (optional):
+// work = work_list_bytes(groups or instances) bytes whose first word is zero (the command pass of the last cull left it so); zero_mask (optional):
 // the ballot words, of which the pre-pass zeroes those of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,

@@ -129,7 +129,8 @@ hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges
                                 float4 *spheres, hipStream_t st);
 // sphere m encloses the meshlets [m, m + 64), hence every 64-meshlet group that starts at meshlet m (range_sphere_bytes(n_meshlets))
 hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st);
-// The single-view pre-pass: `work` = work_list_bytes(...) bytes, first word zeroed by the caller.  zero_mask != nullptr:
+// The single-view pre-pass: `work` = work_list_bytes(...) bytes whose first word is zero (at allocation, and again by
+// the command pass of every cull: launch_emit_commands).  zero_mask != nullptr:
 // the pre-pass also zeroes the ballot words of the groups it drops.
 hipError_t launch_instance_precull(const SceneDev &s, const float4 *spheres, bool per_instance_sphere, const uint32_t *group_base,
                                    const ViewConst &v, const ViewConst *view_dev, uint32_t *work, uint64_t *zero_mask,
