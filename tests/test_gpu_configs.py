@@ -195,6 +195,39 @@ def test_config5_eight_views_8k(mc, O, H, ctx):
     ctx.set_instance_ranges(None, None)
 
 
+def test_eight_8k_pyramids_in_one_call(mc, ctx):
+    """mcull_hiz_build_views at configuration 5's size: eight different 8192^2 images into slots 7..0, every level of every
+    slot against the block minima computed on the device (the reduction nests exactly for a power-of-two image)."""
+    import ctypes
+
+    w = h = 8192
+    levels, lw, lh, loff, total_floats = mc.hiz_layout(w, h)
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    images = [torch.rand((h, w), device="cuda", generator=gen) for _ in range(8)]
+    images[3][4097, 13] = float("inf")
+    images[5][0, 0] = -0.0
+    torch.cuda.synchronize()
+    slots = list(range(7, -1, -1))
+    ctx.hiz_build_views([d.data_ptr() for d in images], views=slots, width=w, height=h, mem=mc.MEM_DEVICE)
+    ctx.synchronize()
+    hip = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            hip = ctypes.CDLL(line.split()[-1])
+            break
+    pyr_dev = torch.empty(total_floats, device="cuda", dtype=torch.float32)
+    for slot, d in zip(slots, images):
+        ptr, nfl = ctx.hiz_pyramid_ptr(slot)
+        assert nfl == total_floats
+        assert hip.hipMemcpy(ctypes.c_void_p(pyr_dev.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(total_floats * 4), 3) == 0
+        cur = d
+        for k in range(levels):
+            lvl = pyr_dev[loff[k]: loff[k] + lw[k] * lh[k]].view(lh[k], lw[k])
+            assert torch.equal(lvl.view(torch.int32), cur.view(torch.int32)), "slot %d level %d" % (slot, k)
+            if k + 1 < levels:
+                cur = -torch.nn.functional.max_pool2d(-cur[None, None], 2)[0, 0]
+
+
 def test_multi_view_pass_equals_separate_culls(mc, O, H, ctx, kitten):
     """mcull_cull_views: one pass over the bounds for several views gives, per view, exactly what a
     separate mcull_cull gives (mask, list, commands, count) - shared kitten mesh with per-view tests
