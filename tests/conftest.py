@@ -64,6 +64,17 @@ def config1(O):
     return dict(globals=z["globals"].view(O.GLOBALS), transforms=z["transforms"].view(O.TRANSFORM))
 
 
+def loaded_hip_runtime():
+    """The HIP runtime this process has already loaded (torch's or the system's: whichever libmcull.so bound to), as a
+    ctypes handle - not a second copy opened by soname."""
+    import ctypes
+
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return ctypes.CDLL(line.split()[-1])
+    return ctypes.CDLL("libamdhip64.so")
+
+
 class Forced:
     """The library's evaluation switches (MCULL_* environment variables, read when a context is created) that the whole
     test run was started under.  The parity tests run under whatever is forced and compare outputs only; assertions on

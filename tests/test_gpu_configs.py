@@ -156,7 +156,8 @@ def test_config5_eight_views_8k(mc, O, H, ctx):
         views.append((g, d))
     ctx.synchronize()
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so.7")
+    from conftest import loaded_hip_runtime
+    hip = loaded_hip_runtime()
     pyr_dev = torch.empty(total_floats, device="cuda", dtype=torch.float32)
     host_pyr = {}
     for v, (g, d) in enumerate(views):
@@ -210,11 +211,8 @@ def test_eight_8k_pyramids_in_one_call(mc, ctx):
     slots = list(range(7, -1, -1))
     ctx.hiz_build_views([d.data_ptr() for d in images], views=slots, width=w, height=h, mem=mc.MEM_DEVICE)
     ctx.synchronize()
-    hip = None
-    for line in open("/proc/self/maps"):
-        if "libamdhip64" in line:
-            hip = ctypes.CDLL(line.split()[-1])
-            break
+    from conftest import loaded_hip_runtime
+    hip = loaded_hip_runtime()
     pyr_dev = torch.empty(total_floats, device="cuda", dtype=torch.float32)
     for slot, d in zip(slots, images):
         ptr, nfl = ctx.hiz_pyramid_ptr(slot)

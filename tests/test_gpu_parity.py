@@ -261,7 +261,8 @@ def test_hiz_large_closed_form(mc, ctx):
     assert n == total and levels == 14
     pyr = torch.empty(total, device="cuda", dtype=torch.float32)
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    from conftest import loaded_hip_runtime
+    hip = loaded_hip_runtime()
     assert hip.hipMemcpy(ctypes.c_void_p(pyr.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(total * 4), 3) == 0
     cur = d
     for k in range(levels):
@@ -423,7 +424,8 @@ def test_ext_command_form(mc, O, ctx, kitten, config1):
             assert not rest.any()
         assert r.first_task
         first = np.zeros(n, dtype="<u4")
-        hip = ctypes.CDLL("libamdhip64.so.7")
+        from conftest import loaded_hip_runtime
+        hip = loaded_hip_runtime()
         ctx.synchronize()
         assert hip.hipMemcpy(ctypes.c_void_p(first.ctypes.data), ctypes.c_void_p(r.first_task), ctypes.c_size_t(n * 4), 2) == 0
         assert np.array_equal(first, ref.commands["firstTask"])
