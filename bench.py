@@ -457,15 +457,17 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         n_rows = max(shard_range(n_scene, world, r)[1] for r in range(world))
     tests = mc.TEST_FRUSTUM | mc.TEST_CONE
     views = [g]
-    cameras = None
-    if args.moving_camera and workload == "config4":
+    def orbit():
         # a different Globals every step: the eye on a slow orbit (0.2 degrees per step, back and forth over 64 steps), so the
         # list an earlier cull reported is off by a few per cent and the mask pass's second launch has real work
-        cameras = []
+        cams = []
         for k in range(64):
             a = np.deg2rad(0.2 * (k if k < 32 else 64 - k))
             ex, ey = 51.0 * np.cos(a) - 54.4 * np.sin(a), 51.0 * np.sin(a) + 54.4 * np.cos(a)
-            cameras.append(env.host.create_globals(eye=(ex, ey, 40.8), fov_deg=args.fov, width=3840, height=2160, flip_y=not args.unflipped))
+            cams.append(env.host.create_globals(eye=(ex, ey, 40.8), fov_deg=args.fov, width=3840, height=2160, flip_y=not args.unflipped))
+        return cams
+
+    cameras = orbit() if args.moving_camera and workload == "config4" else None
     depth = None
     if use_hiz:
         tests |= mc.TEST_HIZ
@@ -602,6 +604,15 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
     if os.environ.get("MCULL_BENCH_HOST_TIMES") and rank == 0:
         print("host time per step: cull enqueue %.1f us, gather enqueue %.1f us (%d steps incl. warm-up)"
               % (host_s[0] / host_s[2] * 1e6, host_s[1] / host_s[2] * 1e6, host_s[2]), file=sys.stderr)
+    moving_ms = None
+    if workload == "config4" and cameras is None and not multi and not args.instances and not args.meshlets_per_instance:
+        # the same step under a camera that moves (a short leg beside the headline figure, which repeats one camera)
+        cameras = orbit()
+        n_m = min(steps, 64)
+        el_m, _ = env.timed(step, steps=n_m, warmup=2)
+        moving_ms = el_m / n_m * 1e3
+        cameras = None
+        views[0] = g
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
     for k in range(min(steps, 10)):
@@ -663,7 +674,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
                 precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances",
                              **({"group_level": {"dropped": grp_dropped, "tested": grp_tested}} if grp_tested else {})),
-                value=job_pairs * n_views / (elapsed / steps) / 1e9, gather_mode=env.gather_mode,
+                value=job_pairs * n_views / (elapsed / steps) / 1e9, gather_mode=env.gather_mode, moving_ms=moving_ms,
                 scene=(cone, sphere, xf, off, cnt))
 
 
@@ -730,6 +741,8 @@ def run_cull(env, workload):
                                        ["ordered", "wave-atomic", "block-atomic"][args.compaction]))
         out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", r["value"], r["elapsed"], r["steps"], name, extra_cfg)
         out["scaling"] = r["scaling"]
+        if r["moving_ms"] is not None:
+            out["moving_camera_ms_per_step"] = round(r["moving_ms"], 4)  # 0.2 degrees of orbit per step: every cull's list differs from the last one's
         traffic, traffic_src = pmc_traffic(args, workload, n_inst, per)
         out["roofline"] = roofline(algo, k_ms, kernels, traffic, traffic_src,
                                    kernel_ms_single_call=round(r["kernel_ms"], 4),
