@@ -314,3 +314,92 @@ def test_random_views_and_payloads(mc, O, H, contexts, seed):
     ctx.cull(views[v], tests=params[v]["tests"] & 3)
     assert ctx.task_payloads().tobytes() == want.tobytes()
 
+
+
+def _compare(mc, c, ref, n_inst, tag):
+    assert c.download_count() == ref.total, tag
+    assert np.array_equal(c.download_mask(), ref.mask), tag
+    assert c.download_list().tobytes() == ref.list.tobytes(), tag
+    cmds = c.download_commands(n_inst).view(mc.CMD).reshape(-1)
+    assert np.array_equal(cmds["taskCount"], ref.commands["taskCount"]) and np.array_equal(cmds["firstTask"], ref.commands["firstTask"]), tag
+
+
+@pytest.mark.parametrize("seed", range(6 * _SCALE))
+def test_random_large_instances(mc, O, H, seed):
+    """Instances of 32 and more groups - the scenes that get a group level, the meshes' boxes and the pyramid's window
+    tables: meshes that are flat, elongated, curled or scattered (where box and sphere differ most), image sizes that are
+    and are not multiples of the texel reach, depth images from empty to walled, several cameras and test subsets per
+    pyramid, pyramids rebuilt in between.  Everything against the oracle, which tests every pair."""
+    rs = np.random.RandomState(9100 + seed)
+    per = int(rs.choice([2048, 2100, 2560, 3000, 4500]))
+    n_inst = int(rs.choice([8, 40, 120]))
+    cone, sphere = H.synthetic_bounds(per, seed=seed + 5)
+    sphere = sphere.copy()
+    shape = int(rs.randint(0, 4))
+    s = np.arange(per, dtype=np.float64) / per
+    if shape == 0:    # a flat slab
+        sphere[:, :3] = (sphere[:, :3] - 0.5) * np.array([6.0, 5.0, 0.2])
+    elif shape == 1:  # a long bar, consecutive meshlets neighbours
+        sphere[:, 0] = ((s - 0.5) * rs.uniform(5, 40) + rs.normal(0, 0.05, per)).astype("<f4")
+        sphere[:, 1:3] = rs.normal(0, 0.2, (per, 2)).astype("<f4")
+    elif shape == 2:  # a spiral
+        turns = rs.uniform(1, 6)
+        sphere[:, 0] = (4.0 * np.cos(2 * np.pi * turns * s)).astype("<f4")
+        sphere[:, 1] = (4.0 * np.sin(2 * np.pi * turns * s)).astype("<f4")
+        sphere[:, 2] = ((s - 0.5) * rs.uniform(2, 30)).astype("<f4")
+    else:             # unrelated meshlets in a cube
+        sphere[:, :3] = (sphere[:, :3] - 0.5) * rs.uniform(1.0, 8.0)
+    sphere[:, 3] = rs.uniform(0.02, rs.uniform(0.05, 0.6), per).astype("<f4")
+    if rs.rand() < 0.3:   # a few hostile bounds inside some groups
+        k = rs.randint(0, per, 6)
+        sphere[k[0], 3] = -0.1
+        sphere[k[1], 0] = np.inf
+        sphere[k[2], 3] = np.nan
+        cone[k[3], :3] = 0.0
+    t = H.synthetic_transforms(n_inst, extent=float(rs.uniform(5.0, 40.0)), seed=seed + 1)
+    m = t["model"].reshape(n_inst, 4, 4).copy()
+    m[:, :3, :3] *= rs.uniform(0.2, 1.5, n_inst).astype("<f4")[:, None, None]
+    if rs.rand() < 0.4:  # and anisotropic scale on a few
+        k = rs.randint(0, n_inst, max(1, n_inst // 4))
+        m[k, :3, :3] *= rs.uniform(0.3, 2.0, (len(k), 3, 1)).astype("<f4")
+    t["model"] = m.reshape(n_inst, 16)
+    ranged = rs.rand() < 0.4
+    off = np.zeros(n_inst, dtype="<u4")
+    cnt = np.full(n_inst, per, dtype="<u4")
+    if ranged:
+        off = rs.randint(0, per // 8, n_inst).astype("<u4")
+        cnt = (per - off - rs.randint(0, per // 8, n_inst)).astype("<u4")
+    c = _context_with(mc, MCULL_PRECULL_MIN_GROUPS="1", MCULL_PRECULL_ADAPTIVE="0")
+    try:
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        c.set_instance_ranges(off, cnt) if ranged else c.set_instance_ranges(None, None)
+        with np.errstate(all="ignore"):
+            for build in range(2):
+                w = int(rs.choice([640, 1001, 1280, 1920, 333]))
+                h = int(rs.choice([360, 563, 720, 1080, 250]))
+                kind = int(rs.randint(0, 4))
+                depth = H.synthetic_depth(w, h, n_discs=int(rs.randint(1, 24)), seed=seed * 3 + build)
+                if kind == 1:
+                    depth[depth > 0] += np.float32(rs.uniform(0.0, 0.3))
+                    depth[:, : w // int(rs.randint(2, 5))] = np.float32(rs.uniform(0.1, 0.9))
+                elif kind == 2:
+                    depth[:] = np.float32(rs.uniform(0.2, 0.9))
+                    depth[rs.randint(0, h, 40), rs.randint(0, w, 40)] = 0.0  # pinholes in a wall
+                elif kind == 3 and rs.rand() < 0.5:
+                    depth[rs.randint(0, h), rs.randint(0, w)] = np.nan
+                slot = int(rs.randint(0, mc.MAX_VIEWS))
+                c.hiz_build(depth, view=slot)
+                pyr = O.hiz_build(depth)
+                for cam in range(3):
+                    g = H.create_globals(eye=tuple(rs.uniform(-45, 45, 3)), centre=tuple(rs.uniform(-8, 8, 3)),
+                                         fov_deg=float(rs.uniform(25, 95)), z_near=float(rs.choice([0.05, 0.1, 1.0])), width=w, height=h,
+                                         flip_y=bool(rs.rand() < 0.5), meshlet_count=per)
+                    tests = int(rs.choice([7, 7, 5, 4, 6, 3]))
+                    ref = O.cull_scene(O.View(g, pyr, w, h), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=tests)
+                    c.cull(g, tests=tests, hiz_view=slot, write_mask=True)
+                    _compare(mc, c, ref, n_inst, (seed, build, cam, tests, w, h))
+                    dropped, tested = c.precull_group_stats()  # (tested is 0 when the instance level has left nothing)
+                    assert dropped <= int((ref.mask == 0).sum()), "a dropped group has no visible meshlet"
+    finally:
+        c.close()
