@@ -403,3 +403,37 @@ def test_random_large_instances(mc, O, H, seed):
                     assert dropped <= int((ref.mask == 0).sum()), "a dropped group has no visible meshlet"
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
+def test_random_pyramids_of_several_views(mc, O, seed):
+    """mcull_hiz_build_views on random sizes, with the streaming scheme forced so that sizes from 1 024 texels a side take
+    the batched launches (narrower ones fall back to single builds): widths that are and are not multiples of four or of
+    the tile size, 1-6 views into random distinct slots, NaNs and infinities, every level of every slot against the oracle."""
+    import torch
+
+    rs = np.random.RandomState(9900 + seed)
+    w = int(rs.choice([1024, 1028, 1031, 1500, 2049, 2560, 700]))
+    h = int(rs.choice([32, 67, 256, 600, 1025]))
+    n = int(rs.randint(1, 7))
+    slots = [int(x) for x in rs.permutation(mc.MAX_VIEWS)[:n]]
+    images = []
+    for k in range(n):
+        d = rs.uniform(0, 1, (h, w)).astype("<f4")
+        if rs.rand() < 0.5:
+            d.flat[rs.randint(0, h * w, 5)] = [np.nan, np.inf, -np.inf, -0.0, 1e-42]
+        images.append(d)
+    c = _context_with(mc, MCULL_HIZ_STREAM="1")
+    try:
+        dev = [torch.from_numpy(d).to("cuda:0") for d in images]
+        torch.cuda.synchronize()
+        for repeat in range(2):
+            c.hiz_build_views([t.data_ptr() for t in dev], views=slots, width=w, height=h, mem=mc.MEM_DEVICE)
+            for slot, d in zip(slots, images):
+                ref = O.hiz_levels(O.hiz_build(d), w, h)
+                got = c.hiz_download(view=slot)
+                assert len(got) == len(ref)
+                for lvl, (a, b) in enumerate(zip(got, ref)):
+                    assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "seed %d %dx%d slot %d level %d" % (seed, w, h, slot, lvl)
+    finally:
+        c.close()
