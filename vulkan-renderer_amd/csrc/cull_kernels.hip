@@ -556,20 +556,26 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *s
 // +inf with R) - the box that a flat or elongated mesh fills far better than the sphere (range_boxes).
 // sliding: sphere i encloses the meshlets [i, i + 64) of an array of uniform_count meshlets instead - whatever group
 // of at most 64 meshlets starts at meshlet i, of any range, lies inside it.
+// PER_WAVE: one wave per range instead (kWaves ranges per workgroup, n_ranges of them in all; nothing goes through
+// shared memory and no wave waits for another) - the shape for many short ranges: 781 250 ranges of 128 meshlets
+// take 2.3 ms with a workgroup each, most of it workgroup launches and barriers.
+template <bool PER_WAVE>
 __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__restrict__ centre_radius,
                                                               const uint2 *__restrict__ ranges, uint32_t uniform_count,
-                                                              uint32_t sliding, float4 *__restrict__ spheres,
+                                                              uint32_t sliding, uint32_t n_ranges, float4 *__restrict__ spheres,
                                                               float *__restrict__ rmax, float4 *__restrict__ boxes) {
-    __shared__ float s_red[kWaves][6];
-    const uint32_t i = blockIdx.x;
+    __shared__ float s_red[PER_WAVE ? 1 : kWaves][6];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t i = PER_WAVE ? blockIdx.x * kWaves + wave : blockIdx.x;
+    if (PER_WAVE && i >= n_ranges) return;  // whole waves leave, and this form has no barrier
+    const uint32_t rank = PER_WAVE ? lane : threadIdx.x, stride = PER_WAVE ? 64u : (uint32_t)kBlock;
     uint32_t first = ranges ? ranges[i].x : 0u, count = ranges ? ranges[i].y : uniform_count;
     if (sliding) {
         first = i;
         count = uniform_count - i < 64u ? uniform_count - i : 64u;
     }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (count == 0u || count > (1u << 20)) {
-        if (threadIdx.x == 0) {
+        if (rank == 0) {
             spheres[i] = make_float4(0.0f, 0.0f, 0.0f, count ? __builtin_inff() : 0.0f);
             rmax[i] = count ? __builtin_inff() : 0.0f;
             const float h = count ? __builtin_inff() : 0.0f;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
         return;
     }
     float sx = 0.0f, sy = 0.0f, sz = 0.0f, bad = 0.0f, neg = 0.0f;
-    for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
+    for (uint32_t j = rank; j < count; j += stride) {
         const float4 c = centre_radius[first + j];
         sx += c.x; sy += c.y; sz += c.z;
         if (!(fabsf(c.x) < 1.0e18f && fabsf(c.y) < 1.0e18f && fabsf(c.z) < 1.0e18f && fabsf(c.w) < 1.0e18f)) bad = 1.0f;
@@ -589,17 +595,22 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
         sx += __shfl_xor(sx, d, 64); sy += __shfl_xor(sy, d, 64); sz += __shfl_xor(sz, d, 64);
         bad = fmaxf(bad, __shfl_xor(bad, d, 64));
     }
-    if (lane == 0) { s_red[wave][0] = sx; s_red[wave][1] = sy; s_red[wave][2] = sz; s_red[wave][3] = bad; }
-    __syncthreads();
     const float inv = 1.0f / (float)count;
-    const float cx = ((s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0])) * inv;
-    const float cy = ((s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1])) * inv;
-    const float cz = ((s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2])) * inv;
-    bad = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
-    __syncthreads();
+    float cx, cy, cz;
+    if (PER_WAVE) {  // the xor reduction left every lane with the wave's sums
+        cx = sx * inv; cy = sy * inv; cz = sz * inv;
+    } else {
+        if (lane == 0) { s_red[wave][0] = sx; s_red[wave][1] = sy; s_red[wave][2] = sz; s_red[wave][3] = bad; }
+        __syncthreads();
+        cx = ((s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0])) * inv;
+        cy = ((s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1])) * inv;
+        cz = ((s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2])) * inv;
+        bad = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+        __syncthreads();
+    }
     // any point works as the centre; what must hold is the radius, measured from the centre as stored
     float r = 0.0f, rm = 0.0f, hx = 0.0f, hy = 0.0f, hz = 0.0f;
-    for (uint32_t j = threadIdx.x; j < count; j += kBlock) {
+    for (uint32_t j = rank; j < count; j += stride) {
         const float4 c = centre_radius[first + j];
         const float dx = c.x - cx, dy = c.y - cy, dz = c.z - cz;
         // |c - C| + r, each step rounded to nearest: the factor below covers those roundings
@@ -614,10 +625,13 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
         neg = fmaxf(neg, __shfl_xor(neg, d, 64));
         hx = fmaxf(hx, __shfl_xor(hx, d, 64)); hy = fmaxf(hy, __shfl_xor(hy, d, 64)); hz = fmaxf(hz, __shfl_xor(hz, d, 64));
     }
-    if (lane == 0) { s_red[wave][0] = r; s_red[wave][1] = rm; s_red[wave][2] = neg; s_red[wave][3] = hx; s_red[wave][4] = hy; s_red[wave][5] = hz; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        auto top = [&](int k) { return fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k])); };
+    if (!PER_WAVE) {
+        if (lane == 0) { s_red[wave][0] = r; s_red[wave][1] = rm; s_red[wave][2] = neg; s_red[wave][3] = hx; s_red[wave][4] = hy; s_red[wave][5] = hz; }
+        __syncthreads();
+    }
+    if (rank == 0) {
+        const float own[6] = {r, rm, neg, hx, hy, hz};
+        auto top = [&](int k) { return PER_WAVE ? own[k] : fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k])); };
         r = top(0); rm = top(1); neg = top(2);
         r = r * 1.00001f + 1.0e-30f;
         if (bad != 0.0f || !(r < 1.0e18f)) r = __builtin_inff();
@@ -630,6 +644,9 @@ __global__ __launch_bounds__(kBlock) void range_sphere_kernel(const float4 *__re
                                ok ? top(5) * 1.00001f + 1.0e-30f : inf, 0.0f);
     }
 }
+
+// ranges up to this many meshlets get a wave each (16 loads per lane and pass), longer ones a workgroup each
+constexpr uint32_t kRangePerWaveMax = 1024;
 
 constexpr uint32_t kWorkHeader = 64;  // uint32 words in front of a work list: [0] = number of entries (256-byte header)
 // Shape of the pre-pass: one instance per thread, 1 024 threads per workgroup, one list reservation per workgroup.
@@ -2487,11 +2504,18 @@ hipError_t launch_cull_atomic(const SceneDev &s, const ViewConst &v, mcull_visib
 // spheres: n_ranges float4 followed by n_ranges float (range_sphere_bytes)
 size_t range_sphere_bytes(uint32_t n_ranges) { return range_box_offset_bytes(n_ranges) + (size_t)n_ranges * 16; }
 
+// longest_range: no range holds more meshlets (what picks one wave or one workgroup per range)
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
-                                float4 *spheres, hipStream_t st) {
+                                uint32_t longest_range, float4 *spheres, hipStream_t st) {
     if (n_ranges == 0) return hipSuccess;
-    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, 0u, spheres,
-                       reinterpret_cast<float *>(spheres + n_ranges), const_cast<float4 *>(range_boxes(spheres, n_ranges)));
+    float *rmax = reinterpret_cast<float *>(spheres + n_ranges);
+    float4 *boxes = const_cast<float4 *>(range_boxes(spheres, n_ranges));
+    if (n_ranges >= kWaves && longest_range <= kRangePerWaveMax)
+        hipLaunchKernelGGL(range_sphere_kernel<true>, dim3((n_ranges + kWaves - 1) / kWaves), dim3(kBlock), 0, st, centre_radius, ranges,
+                           uniform_count, 0u, n_ranges, spheres, rmax, boxes);
+    else
+        hipLaunchKernelGGL(range_sphere_kernel<false>, dim3(n_ranges), dim3(kBlock), 0, st, centre_radius, ranges, uniform_count, 0u,
+                           n_ranges, spheres, rmax, boxes);
     return hipGetLastError();
 }
 
@@ -2499,8 +2523,9 @@ hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges
 // group that starts at meshlet m
 hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st) {
     if (n_meshlets == 0) return hipSuccess;
-    hipLaunchKernelGGL(range_sphere_kernel, dim3(n_meshlets), dim3(kBlock), 0, st, centre_radius, (const uint2 *)nullptr, n_meshlets, 1u,
-                       spheres, reinterpret_cast<float *>(spheres + n_meshlets), const_cast<float4 *>(range_boxes(spheres, n_meshlets)));
+    hipLaunchKernelGGL(range_sphere_kernel<true>, dim3((n_meshlets + kWaves - 1) / kWaves), dim3(kBlock), 0, st, centre_radius,
+                       (const uint2 *)nullptr, n_meshlets, 1u, n_meshlets, spheres, reinterpret_cast<float *>(spheres + n_meshlets),
+                       const_cast<float4 *>(range_boxes(spheres, n_meshlets)));
     return hipGetLastError();
 }
 

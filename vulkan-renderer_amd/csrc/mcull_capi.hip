@@ -108,6 +108,7 @@ struct mcull_ctx {
     bool have_aos = false, have_bounds = false, have_geometry = false, have_ranges = false;
     bool geometry_checked = false;  // the uploaded meshlets index only inside the uploaded geometry (host check done)
     uint64_t ranged_groups = 0, ranged_pairs = 0, ranged_max_end = 0, ranged_instances = 0;
+    uint32_t ranged_longest = 0;  // meshlets of the longest range
     // instance pre-cull: one enclosing sphere per instance range (ranged scenes) or one for [0, meshletCount);
     // computed on the first cull after the bounds or the ranges changed
     DevBuf range_spheres;
@@ -617,6 +618,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
         return fail(c, MCULL_E_NOMEM, "no host memory for %llu instance ranges", (unsigned long long)n_instances);
     }
     uint64_t groups = 0, pairs = 0, max_end = 0;
+    uint32_t longest = 0;
     for (uint64_t i = 0; i < n_instances; i++) {
         rg[2 * i] = meshlet_offset[i];
         rg[2 * i + 1] = meshlet_count[i];
@@ -625,6 +627,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
         pairs += meshlet_count[i];
         const uint64_t end = (uint64_t)meshlet_offset[i] + meshlet_count[i];
         if (end > max_end) max_end = end;
+        if (meshlet_count[i] > longest) longest = meshlet_count[i];
         if (groups >= 0xffffffffull) return fail(c, MCULL_E_INVALID, "more than 2^32 meshlet groups");
     }
     base[n_instances] = (uint32_t)groups;
@@ -647,6 +650,7 @@ int mcull_set_instance_ranges(mcull_ctx *c, const uint32_t *meshlet_offset, cons
     c->ranged_groups = groups;
     c->ranged_pairs = pairs;
     c->ranged_max_end = max_end;
+    c->ranged_longest = longest;
     c->ranged_instances = n_instances;
     return MCULL_OK;
 }
@@ -925,7 +929,8 @@ int ensure_range_spheres(mcull_ctx *c, const mcull::SceneDev &s, uint32_t unifor
     if (c->spheres_valid && c->spheres_ranged == ranged && (ranged || c->spheres_uniform_count == uniform_count)) return MCULL_OK;
     const uint32_t n_ranges = ranged ? (uint32_t)c->n_instances : 1u;
     if (int rc = ensure(c, c->range_spheres, mcull::range_sphere_bytes(n_ranges))) return rc;
-    HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, uniform_count, (float4 *)c->range_spheres.p, c->stream));
+    HIPCHK(c, mcull::launch_range_spheres(s.centre_radius, s.ranges, n_ranges, uniform_count, ranged ? c->ranged_longest : uniform_count,
+                                          (float4 *)c->range_spheres.p, c->stream));
     c->spheres_valid = true;
     c->spheres_ranged = ranged;
     c->spheres_uniform_count = uniform_count;

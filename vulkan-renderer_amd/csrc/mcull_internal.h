@@ -126,7 +126,7 @@ hipError_t launch_cull_mask(const SceneDev &s, const ViewConst &v, uint64_t *mas
 size_t work_list_bytes(uint64_t units, bool ranged);  // units = groups (ranged scenes) or instances
 size_t range_sphere_bytes(uint32_t n_ranges);  // what launch_range_spheres writes: n float4 spheres, n float largest radii, n float4 boxes
 hipError_t launch_range_spheres(const float4 *centre_radius, const uint2 *ranges, uint32_t n_ranges, uint32_t uniform_count,
-                                float4 *spheres, hipStream_t st);
+                                uint32_t longest_range, float4 *spheres, hipStream_t st);
 // sphere m encloses the meshlets [m, m + 64), hence every 64-meshlet group that starts at meshlet m (range_sphere_bytes(n_meshlets))
 hipError_t launch_group_spheres(const float4 *centre_radius, uint32_t n_meshlets, float4 *spheres, hipStream_t st);
 // The single-view pre-pass: `work` = work_list_bytes(...) bytes whose first word is zero (at allocation, and again by
