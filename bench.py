@@ -761,6 +761,9 @@ def run_cull(env, workload):
             counted = pmc_valu("r03_bench_config3", step_kernels)
             if counted:
                 hbm = out["roofline"]
+                if hbm.get("traffic"):
+                    hbm["traffic_note"] = ("beside the lists the step zeroes the ballot word of every group (1.6 GB) and writes the two "
+                                           "work lists and the listed groups' ballots: bytes the algorithmic figure leaves out")
                 out["roofline"] = valu_roofline(counted, k_ms, kernels)
                 out["roofline"]["hbm"] = hbm
         if workload == "config5" and world == 1 and default_scene and not args.separate_views and (n_inst, per) == (781250, 128):
@@ -852,13 +855,20 @@ def valu_roofline(counted, kernel_ms, kernel_name):
 
 
 def pmc_traffic(args, workload, n_inst, per):
-    """Traffic of one step of the profiled default workload, or None when the workload differs."""
-    if workload != "config4" or (n_inst, per, args.compaction, args.hiz) != (781250, 128, 0, False):
+    """Traffic of one step of a profiled default workload, or None when the workload differs from the profiled one."""
+    if args.no_precull or args.exact or args.compaction or args.tests is not None or args.meshlets_per_instance:
         return None, None
-    if args.no_precull or args.exact:
-        return None, None
-    return pmc_summary_bytes("r03_bench_config4", ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel",
-                                                   "emit_commands_kernel"))
+    if workload == "config4" and (n_inst, per, args.hiz) == (781250, 128, False):
+        return pmc_summary_bytes("r03_bench_config4", ("instance_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel", "compact_kernel",
+                                                       "emit_commands_kernel"))
+    if workload == "config5" and (n_inst, per) == (781250, 128) and not args.separate_views:
+        return pmc_summary_bytes("r03_bench_config5", ("hiz_rows_views_kernel", "hiz_tile_views_kernel", "hiz_top_views_kernel",
+                                                       "classify_views_kernel", "cull_mask_views_kernel", "scan_tiles_views_kernel",
+                                                       "compact_views_kernel", "emit_commands_views_kernel"))
+    if workload == "config3" and (n_inst, args.c3_mesh) == (1_000_000, "proxy"):
+        return pmc_summary_bytes("r03_bench_config3", ("instance_precull_kernel", "group_precull_kernel", "cull_mask_kernel", "scan_tiles_kernel",
+                                                       "compact_kernel", "emit_commands_kernel", "zero_words_kernel"))
+    return None, None
 
 
 def cpu_baseline_cull(cone, sphere, xf, off, cnt, g, tests, n_inst, per, depth, hiz_size, workload):
@@ -916,7 +926,7 @@ def run_hiz(env):
         out = base_line(env, "Hi-Z pyramid pixels reduced/sec", "Gpixel/s", value, elapsed, args.steps,
                         "Hi-Z min pyramid of a %dx%d depth image, %d levels%s"
                         % (w, h, levels, " (replicas: every GPU builds its own)" if env.world > 1 else ""))
-        traffic, src = pmc_summary_bytes("r01_bench_hiz", ("hiz_rows_kernel", "hiz_tile_kernel")) if (w, h) == (8192, 8192) else (None, None)
+        traffic, src = pmc_summary_bytes("r03_bench_hiz", ("hiz_rows_kernel", "hiz_tile_kernel")) if (w, h) == (8192, 8192) else (None, None)
         out["roofline"] = roofline(algo, dev_ms / args.steps, "hiz_rows_kernel + hiz_tile_kernel", traffic, src,
                                    bytes_per_pixel=round(algo / (w * h), 3))
         if not args.no_cpu_baseline and env.world == 1:

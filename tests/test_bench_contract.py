@@ -29,7 +29,8 @@ def test_committed_bench_line_has_the_contract_fields(path):
     r = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    if r["bound"] == "valu":
+    issue_bound = r["bound"] == "valu"
+    if issue_bound:
         # a pass bound by vector-instruction issue: counted instructions x 4 cycles over the 1 024 SIMDs at the measured
         # clock; the byte figure stays beside it
         assert r["unit"] == "G wave-instr/s" and 1800.0 < r["clock_mhz"] < 2600.0 and abs(r["peak"] - 1024 * r["clock_mhz"] / 4e3) < 0.1
@@ -40,8 +41,11 @@ def test_committed_bench_line_has_the_contract_fields(path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.0 < r["frac"] < 1.0
-    if r["traffic"] is not None:  # measured bytes within a factor of the algorithmic ones
-        assert 0.5 < r["traffic"] / r["algorithmic_bytes"] < 1.5
+    if r["traffic"] is not None:
+        # measured bytes within a factor of the algorithmic ones; the issue-bound line's count leaves out what its step
+        # moves beside the lists (the ballot words zeroed for every group, the work lists) and says so
+        assert 0.5 < r["traffic"] / r["algorithmic_bytes"] < (1.5 if not issue_bound else 2.0)
+        assert not issue_bound or "traffic_note" in r
     if "all_bounds" in r:  # lines of a cull with the instance pre-cull: the figure with every bound counted as read
         a = r["all_bounds"]
         assert a["algorithmic_bytes"] - a["bounds_bytes_not_touched"] <= r["algorithmic_bytes"] + 4 * j["config"].get("pairs_reaching_hiz", 0)

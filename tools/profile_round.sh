@@ -24,6 +24,13 @@ trace() {
   python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --out-dir $O > /dev/null || exit 1
   echo "traced $name"
 }
+summ() {  # the summary of one workload from whatever passes of it this call has made so far
+  local name=$1 more=""
+  [ -d /tmp/pmc_${name}_FETCH_SIZE ] && more="$more --fetch /tmp/pmc_${name}_FETCH_SIZE"
+  [ -d /tmp/pmc_${name}_WRITE_SIZE ] && more="$more --write /tmp/pmc_${name}_WRITE_SIZE"
+  [ -d /tmp/pmc_${name}_insts ] && more="$more --insts /tmp/pmc_${name}_insts"
+  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name $more --out-dir $O > /dev/null
+}
 pmc() {
   local name=$1; shift
   cd /tmp && export TMPDIR=/tmp
@@ -32,7 +39,7 @@ pmc() {
     timeout -s KILL 120 rocprofv3 --pmc $c --kernel-include-regex "mcull" --output-format csv -d /tmp/pmc_${name}_$c -o p -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; exit 1; }
     echo "counted $c for $name"
   done
-  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --fetch /tmp/pmc_${name}_FETCH_SIZE --write /tmp/pmc_${name}_WRITE_SIZE --out-dir $O > /dev/null || exit 1
+  summ $name || exit 1
 }
 insts() {
   local name=$1; shift
@@ -40,13 +47,13 @@ insts() {
   rm -rf /tmp/pmc_${name}_insts
   timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-include-regex "mcull" --output-format csv -d /tmp/pmc_${name}_insts -o p -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; exit 1; }
   echo "counted instructions for $name"
-  python3 $R/tools/summarize_profile.py --tag ${T}_bench_$name --stats /tmp/kt_$name --insts /tmp/pmc_${name}_insts --out-dir $O > /dev/null || exit 1
+  summ $name || exit 1
 }
 for w in $WHAT; do
   case $w in
     lines)
       # bench.py quotes the counter passes of the committed summaries: after `traces pmc insts` of the same call they are these
-      cp $O/${T}_bench_config[345]_summary.json $R/profiles/ 2>/dev/null
+      cp $O/${T}_bench_config[345]_summary.json $O/${T}_bench_hiz_summary.json $R/profiles/ 2>/dev/null
       line config4 || exit 1
       line config4_hiz_flipped --hiz || exit 1
       line config4_hiz_unflipped --hiz --unflipped || exit 1
@@ -74,6 +81,9 @@ for w in $WHAT; do
       ;;
     pmc)
       pmc config4 || exit 1
+      pmc config3 --workload config3 || exit 1
+      pmc config5 --workload config5 || exit 1
+      pmc hiz --workload hiz || exit 1
       ;;
     insts)  # after `traces` in the same call: the summary is rewritten with the durations beside the counters
       insts config3 --workload config3 || exit 1

@@ -103,6 +103,10 @@ def main():
             if ns and k.get("GRBM_GUI_ACTIVE"):
                 row["counter_pass_avg_us"] = round(ns / n / 1e3, 3)
                 row["clock_mhz"] = round(k["GRBM_GUI_ACTIVE"] / 8.0 / ns * 1e3, 1)
+    kept = os.path.join(ROOT, "profiles", "%s_summary.json" % args.tag)
+    if os.path.exists(kept):  # hand-written notes of the committed summary ("_..." keys) stay
+        with open(kept) as f:
+            summary.update({k: v for k, v in json.load(f).items() if k.startswith("_")})
     with open(os.path.join(out_dir, "%s_summary.json" % args.tag), "w") as o:
         json.dump(summary, o, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
