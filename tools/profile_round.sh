@@ -3,7 +3,7 @@
 # Writes <tag>_bench_<workload>.json (bench lines), <tag>_bench_<workload>_kernel_stats.csv and _summary.json
 # (rocprofv3 kernel trace of the same command, and for the headline the FETCH_SIZE / WRITE_SIZE passes) under
 # gpurun_out/<tag>/; what is to be kept is then copied to profiles/.  Every GPU step has its own time limit and
-# a failing step ends the script.
+# a failing step ends the script.  ONLY=<regex> restricts every stage to the workloads whose name matches.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$1; shift
@@ -12,12 +12,14 @@ O=$R/gpurun_out/$T
 mkdir -p $O
 line() {
   local name=$1; shift
+  [[ $name =~ ^(${ONLY:-.*})$ ]] || return 0
   cd $R
   timeout -k 10 280 python bench.py "$@" > $O/${T}_bench_$name.json 2> $O/$name.err || { tail -5 $O/$name.err; exit 1; }
   python3 -c "import json,sys; j=json.load(open(sys.argv[1])); print(sys.argv[2], j['ms_per_step'], 'ms', j['value'], j['unit'], 'frac', j['roofline']['frac'])" $O/${T}_bench_$name.json $name
 }
 trace() {
   local name=$1; shift
+  [[ $name =~ ^(${ONLY:-.*})$ ]] || return 0
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/kt_$name
   timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -o p -- python3 $R/bench.py --no-cpu-baseline "$@" > /tmp/kt_$name.log 2>&1 || { tail -5 /tmp/kt_$name.log; exit 1; }
@@ -33,6 +35,7 @@ summ() {  # the summary of one workload from whatever passes of it this call has
 }
 pmc() {
   local name=$1; shift
+  [[ $name =~ ^(${ONLY:-.*})$ ]] || return 0
   cd /tmp && export TMPDIR=/tmp
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${name}_$c
@@ -43,6 +46,7 @@ pmc() {
 }
 insts() {
   local name=$1; shift
+  [[ $name =~ ^(${ONLY:-.*})$ ]] || return 0
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/pmc_${name}_insts
   timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-include-regex "mcull" --output-format csv -d /tmp/pmc_${name}_insts -o p -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-ms 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1 || { tail -5 /tmp/pmc_$name.log; exit 1; }
@@ -53,7 +57,7 @@ for w in $WHAT; do
   case $w in
     lines)
       # bench.py quotes the counter passes of the committed summaries: after `traces pmc insts` of the same call they are these
-      cp $O/${T}_bench_config[345]_summary.json $O/${T}_bench_hiz_summary.json $R/profiles/ 2>/dev/null
+      cp $O/${T}_bench_config[345]_summary.json $O/${T}_bench_hiz_summary.json $O/${T}_bench_depth_summary.json $R/profiles/ 2>/dev/null
       line config4 || exit 1
       line config4_hiz_flipped --hiz || exit 1
       line config4_hiz_unflipped --hiz --unflipped || exit 1
@@ -88,6 +92,7 @@ for w in $WHAT; do
     insts)  # after `traces` in the same call: the summary is rewritten with the durations beside the counters
       insts config3 --workload config3 || exit 1
       insts config5 --workload config5 || exit 1
+      insts depth --workload depth || exit 1
       ;;
   esac
 done
