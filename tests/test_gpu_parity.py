@@ -360,6 +360,52 @@ def test_empty_and_degenerate_scenes(mc, O, H, kitten, config1, compaction):
     c.close()
 
 
+@pytest.mark.parametrize("n_inst", [700, 66000])
+def test_caller_list_at_any_entry_offset_inside_a_cache_line(mc, H, n_inst):
+    """The scatter pass deals its 16-byte stores from 128-byte line boundaries of the LIST's address: a caller's list may
+    start at any 8-byte entry inside a line.  Both store forms (plain for small lists, non-temporal above 64 MB of
+    pairs), with and without a capacity that cuts the list, canaries on both sides."""
+    import torch
+
+    per = 128
+    cone, sphere = H.synthetic_bounds(n_inst * per, seed=3)
+    t = H.synthetic_transforms(n_inst, extent=30.0, seed=4)
+    g = H.create_globals(width=1920, height=1080)
+    c = mc.Context(0)
+    c.upload_bounds_soa(cone, sphere)
+    c.upload_transforms(t)
+    c.set_instance_ranges(np.arange(n_inst, dtype=np.uint32) * per, np.full(n_inst, per, dtype=np.uint32))
+    c.cull(g, tests=3)
+    total = c.download_count()
+    want = torch.from_numpy(c.download_list().view("<i4").reshape(-1, 2).copy()).cuda()
+    cmds_want = c.download_commands(n_inst).copy()
+    assert 1000 < total < n_inst * per
+    buf = torch.empty((total + 64, 2), dtype=torch.int32, device="cuda")
+    for lead in (1, 2, 7, 15):
+        for cap in (total, total - 37):
+            buf.fill_(-1)
+            torch.cuda.synchronize()
+            c.cull(g, tests=3, list_ptr=buf.data_ptr() + 8 * lead, list_capacity=cap)
+            assert c.download_count() == total
+            assert bool((buf[:lead] == -1).all()) and bool((buf[lead + cap:] == -1).all()), "stores outside the list"
+            assert torch.equal(buf[lead:lead + cap], want[:cap])
+            assert np.array_equal(c.download_commands(n_inst), cmds_want)
+    # the same through the other entry points that scatter into caller-owned lists
+    bufs = [torch.full((total + 64, 2), -1, dtype=torch.int32, device="cuda") for _ in range(3)]
+    cmds = torch.zeros((n_inst, 2), dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    leads = (3, 9, 5)
+    c.cull_views([g, g], [dict(tests=3, list_ptr=bufs[v].data_ptr() + 8 * leads[v], list_capacity=total) for v in range(2)])
+    c.cull_static(g, bufs[2].data_ptr() + 8 * leads[2], total, cmds.data_ptr(), count.data_ptr(), tests=3)
+    c.synchronize()
+    for v in range(3):
+        assert bool((bufs[v][:leads[v]] == -1).all()) and bool((bufs[v][leads[v] + total:] == -1).all())
+        assert torch.equal(bufs[v][leads[v]:leads[v] + total], want)
+    assert int(count.item()) == total
+    c.close()
+
+
 def test_task_group_command_form(mc, O, ctx, kitten, config1):
     """MCULL_CMD_NV_TASK_GROUPS: the NV record at the reference's granularity, taskCount = ceil(visible_i / 32) task
     workgroups of 32 (Engine.cpp:1475-1483), firstTask = the draw's offset in the list as in the per-meshlet form."""
