@@ -72,6 +72,7 @@ for w in $WHAT; do
       line config1 --workload config1 --graph || exit 1
       line depth --workload depth || exit 1
       line bounds --workload bounds || exit 1
+      line meshbuild --workload meshbuild || exit 1
       ;;
     traces)
       trace config4 --steps 50 --warmup 10 || exit 1
