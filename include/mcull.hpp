@@ -21,8 +21,10 @@
 //   optimizeGeometry             :338-471      Mesh::optimizeGeometry
 //   createMeshlets               :548-628      Mesh::createMeshlets (host) / Culler::createMeshlets (GPU, with bounds)
 //   ... run once, then Mesh::save / Culler::loadScene (cache file)
+//   (no counterpart: one device, :658-666)     MultiGpuCuller (one thread, all GPUs) / RankExchange (one process per GPU)
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <iostream>
 #include <stdexcept>
@@ -389,6 +391,54 @@ private:
     uint64_t instances_ = 0;
     uint32_t stride_ = 8;
     std::vector<uint64_t> cuts_;
+};
+
+// The other multi-GPU form: one PROCESS per GPU.  Every rank culls its contiguous shard of the instances with a Culler
+// of its own and lets the cull write its visible count behind its n commands (mcull_cull_params.total = record n of
+// the command buffer); gatherCommands then exchanges those n + 1 records of every rank with one RCCL all-gather and
+// rebases the gathered firstTask values on the same stream, so that every rank holds the scene-wide commands.  The
+// reference draws on one device (Engine.cpp:658-666).
+class RankExchange {
+public:
+    using UniqueId = std::array<unsigned char, MCULL_RCCL_UNIQUE_ID_BYTES>;
+    // rank 0 makes the id and ships it to the other ranks by whatever means the host has (a file, a socket, MPI)
+    static UniqueId createId() {
+        UniqueId id{};
+        check(mcull_rccl_unique_id(id.data()));
+        return id;
+    }
+    // collective: returns when all `world` ranks have called it; makes deviceOrdinal the current device
+    RankExchange(const UniqueId &id, int world, int rank, int deviceOrdinal) : world_(world), rank_(rank) {
+        check(mcull_rccl_comm_create(id.data(), world, rank, deviceOrdinal, &comm_));
+    }
+    ~RankExchange() {
+        if (comm_) mcull_rccl_comm_destroy(comm_);
+    }
+    RankExchange(const RankExchange &) = delete;
+    RankExchange &operator=(const RankExchange &) = delete;
+
+    int world() const { return world_; }
+    int rank() const { return rank_; }
+    // first instance of rank r when `instances` are split evenly
+    static uint64_t firstInstance(uint64_t instances, int world, int r) { return instances * (uint64_t)r / (uint64_t)world; }
+
+    // sendBlock: this rank's rowsPerRank + 1 records {taskCount, firstTask}, the last one its count; gathered: room for
+    // world such blocks; totals / bases: world uint64 each (all device memory of the current device); stream: a
+    // hipStream_t.  Two enqueues, no host synchronisation.
+    void gatherCommands(void *stream, const void *sendBlock, void *gathered, uint64_t rowsPerRank, uint64_t *totals, uint64_t *bases) {
+        check(mcull_allgather_commands(comm_, stream, sendBlock, gathered, (uint32_t)world_, rowsPerRank, totals, bases));
+    }
+    void *handle() const { return comm_; }
+
+private:
+    static void check(int status) {
+        if (status == MCULL_OK) return;
+        const std::string msg = std::string("mcull error: ") + mcull_status_string(status) + " (" + mcull_collective_last_error() + ")";
+        std::cerr << msg << std::endl;
+        throw std::runtime_error(msg);
+    }
+    void *comm_ = nullptr;
+    int world_ = 1, rank_ = 0;
 };
 
 }  // namespace mcull

@@ -258,8 +258,12 @@ def test_cpp_wrapper_compiles_and_throws_like_vk_check(tmp_path, mc):
     src.write_text(r"""
 #include "mcull.hpp"
 #include <cstdio>
-int main() {
+int main(int argc, char **) {
     std::printf("version %d\n", mcull_version());
+    if (argc > 7) {  // compiled, never run here: the one-process-per-GPU exchange
+        mcull::RankExchange x(mcull::RankExchange::createId(), 1, 0, 0);
+        x.gatherCommands(nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+    }
     try { mcull::Culler c(0); std::printf("created\n"); }
     catch (const std::runtime_error &e) { std::printf("threw %s\n", e.what()); }
     return 0;

@@ -1,7 +1,8 @@
 """The C++ host mirror (include/mcull.hpp) end to end on the GPU: examples/engine_frame.cpp, built with g++,
 loads a scene cache file, records one frame with the reference-named methods and prints the visible
 count and FNV-1a hashes of the draw list and commands, which must equal the oracle's frame; it also replays
-the frame as a HIP graph under a moving camera and splits the scene over three shards."""
+the frame as a HIP graph under a moving camera, splits the scene over three shards and runs the one-process-per-GPU
+exchange in a world of one."""
 import os
 import subprocess
 
@@ -35,5 +36,6 @@ def test_cpp_host_mirror_records_a_frame(tmp_path, mc, O, kitten, config1):
     assert want in out.stdout, (want, out.stdout)
     assert "device globals frame equal" in out.stdout
     assert "three shards equal" in out.stdout
+    assert "rank exchange equal" in out.stdout  # RankExchange over the system's RCCL, a world of one rank
     assert out.stdout.count("graph frame") == 3
     assert "threw mcull error: MCULL_E_IO" in out.stdout and "mcull error" in out.stderr
