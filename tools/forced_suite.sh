@@ -15,9 +15,10 @@ declare -A COMBO=(
   [hiz_stream]="MCULL_HIZ_STREAM=1"
   [hiz_tiles]="MCULL_HIZ_TILES=1"
   [hiz_single]="MCULL_HIZ_SINGLE_LAUNCH=1"
+  [short_rounds]="MCULL_COMPACT_SHORT_ROUNDS=1"
   [all_off]="MCULL_FORCE_STREAMING=1 MCULL_PRECULL_FLAGS=0 MCULL_PRECULL_GROUPS=0 MCULL_PRECULL_ADAPTIVE=0 MCULL_HIZ_STRIPS=0 MCULL_HIZ_WINDOWS=0"
 )
-NAMES=${*:-streaming no_flags no_groups no_adaptive no_strips no_windows hiz_stream hiz_tiles hiz_single all_off}
+NAMES=${*:-streaming no_flags no_groups no_adaptive no_strips no_windows hiz_stream hiz_tiles hiz_single short_rounds all_off}
 for n in $NAMES; do
   env ${COMBO[$n]} timeout -k 10 400 python -u -m pytest tests -q -m gpu --timeout 200 --timeout-method thread -p no:cacheprovider > gpurun_out/forced_$n.log 2>&1
   rc=$?

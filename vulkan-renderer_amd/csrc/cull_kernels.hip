@@ -29,10 +29,12 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kTileGroups = 256;  // groups per compaction tile = 16384 meshlet-instances
 constexpr uint32_t kRoundGroups = 64;   // groups staged in LDS per output round of the scatter pass (32 KiB)
-// ... of its tile-walking form, which waits for latency, not for bytes: 16 KiB, seven workgroups per CU instead of four
-// (1 M instances of one mesh: 1.72 -> 1.37 ms for the pass; 16 groups: 1.47 ms; the next tile's ballots and offset asked
-// for one tile ahead on top of it: no change)
-constexpr uint32_t kLoopRoundGroups = 32;
+// ... of the forms that wait for latency, not for bytes: 16 KiB, seven workgroups per CU instead of four.  The tile-walking
+// form (1 M instances of one mesh: 1.72 -> 1.37 ms for the pass; 16 groups: 1.47 ms; the next tile's ballots and offset
+// asked for one tile ahead on top of it: no change), and SHORT, the one-workgroup-per-tile form behind a work list that
+// is expected to hold less than a quarter of the scene's groups (100 M pairs with the occlusion test, 4 % visible:
+// 51 -> 37 us for the pass; a half-visible list loses with it: 90 -> 97 us).
+constexpr uint32_t kShortRoundGroups = 32;
 constexpr uint32_t kScanMinTiles = 1024;  // scenes with more tiles get their tile offsets from scan_tiles_kernel
 constexpr int kScanBlock = 1024;          // threads of that kernel's single workgroup
 constexpr int kScanPerThread = 8;         // consecutive counters per thread and iteration
@@ -1876,7 +1878,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_tiles_views_kernel(ViewTails 
 // workgroups walks the tiles with a stride instead of one workgroup per tile, so that an empty tile costs a scalar load
 // and a branch, not a workgroup (1 M instances of one mesh, 851 000 tiles: 1.5 ms of this pass were workgroups that
 // started and left).
-template <bool NT, bool LOOP>
+template <bool NT, bool LOOP, bool SHORT>
 __device__ __forceinline__ void compact_body(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
@@ -1886,7 +1888,7 @@ __device__ __forceinline__ void compact_body(
     __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
     __shared__ uint32_t s_wave[kWaves];
     __shared__ unsigned long long s_sum[kWaves];
-    constexpr uint32_t kRound = LOOP ? kLoopRoundGroups : kRoundGroups;  // groups staged per output round
+    constexpr uint32_t kRound = (LOOP || SHORT) ? kShortRoundGroups : kRoundGroups;  // groups staged per output round
     __shared__ unsigned long long s_stage[kRound * 64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2026,13 +2028,13 @@ __device__ __forceinline__ void compact_body(
     }
 }
 
-template <bool NT, bool LOOP = false>
+template <bool NT, bool LOOP = false, bool SHORT = false>
 __global__ __launch_bounds__(kBlock) void compact_kernel(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
     unsigned long long *__restrict__ total, uint32_t split, uint32_t skip_empty) {
-    compact_body<NT, LOOP>(mask, tile_counts, tile_offsets, group_rec, groups_per_instance, n_groups, list, capacity, inst_first, total,
+    compact_body<NT, LOOP, SHORT>(mask, tile_counts, tile_offsets, group_rec, groups_per_instance, n_groups, list, capacity, inst_first, total,
                            split, skip_empty);
 }
 
@@ -2041,7 +2043,7 @@ __global__ __launch_bounds__(kBlock) void compact_views_kernel(ViewTails tails, 
                                                                uint32_t groups_per_instance, uint32_t n_groups, uint32_t split,
                                                                uint32_t skip_empty) {
     const ViewTail &t = tails.t[blockIdx.y];
-    compact_body<NT, LOOP>(t.mask, t.tile_counts, with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_rec,
+    compact_body<NT, LOOP, false>(t.mask, t.tile_counts, with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_rec,
                            groups_per_instance, n_groups, t.list, t.capacity, t.inst_first, (unsigned long long *)t.total, split, skip_empty);
 }
 
@@ -2408,7 +2410,7 @@ bool skips_empty_tiles(const SceneDev &s) { return needs_tile_offsets(s.n_groups
 
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
-                          uint64_t *total, bool streaming, hipStream_t st) {
+                          uint64_t *total, bool streaming, hipStream_t st, bool short_rounds) {
     const uint32_t tiles = tile_count_for(s.n_groups);
     const uint32_t skip_empty = skips_empty_tiles(s) ? 1u : 0u;
     // One workgroup per tile: splitting a tile over 2 / 4 workgroups (each redoing the offset sum and
@@ -2436,7 +2438,15 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
                                s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first, (unsigned long long *)total, 1u, 1u);
         return hipGetLastError();
     }
-    if (streaming)
+    if (short_rounds && streaming)
+        hipLaunchKernelGGL((compact_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
+                           s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
+                           (unsigned long long *)total, split, skip_empty);
+    else if (short_rounds)
+        hipLaunchKernelGGL((compact_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
+                           s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
+                           (unsigned long long *)total, split, skip_empty);
+    else if (streaming)
         hipLaunchKernelGGL(compact_kernel<true>, dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
                            (unsigned long long *)total, split, skip_empty);

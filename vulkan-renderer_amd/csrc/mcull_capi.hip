@@ -130,6 +130,8 @@ struct mcull_ctx {
     volatile uint32_t *kept_host = nullptr;  // MCULL_MAX_VIEWS words, hipHostMalloc (mapped): [0] single-view culls, [1] multi-view, [2] group level
     uint32_t *kept_dev = nullptr;            // the same memory as the device sees it
     bool precull_adaptive = true;
+    // the scatter pass's rounds of 32 groups for lists expected to be sparse: -1 = by the list estimate, MCULL_COMPACT_SHORT_ROUNDS=1 / 0 = always / never
+    int compact_short = -1;
 
     // Hi-Z
     HizSlot hiz[MCULL_MAX_VIEWS];
@@ -398,6 +400,7 @@ int mcull_create(int device_ordinal, void *stream, mcull_ctx **out) {
     c->force_streaming = fs && fs[0] == '1';
     if (const char *pm = std::getenv("MCULL_PRECULL_MIN_GROUPS")) c->precull_min_groups = std::strtoull(pm, nullptr, 10);
     if (const char *pa = std::getenv("MCULL_PRECULL_ADAPTIVE")) c->precull_adaptive = pa[0] != '0';
+    if (const char *cs = std::getenv("MCULL_COMPACT_SHORT_ROUNDS")) c->compact_short = cs[0] != '0' ? 1 : 0;
     void *host_words = nullptr, *dev_words = nullptr;
     if (hipHostMalloc(&host_words, MCULL_MAX_VIEWS * 4, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(&dev_words, host_words, 0) != hipSuccess) {
@@ -1079,9 +1082,12 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
 
 // scatter + commands of the ordered path (after the mask pass has filled mask and tile counters)
 int launch_ordered_tail(mcull_ctx *c, mcull_ctx::ViewOut &o, const CullPlan &pl) {
+    // a work list expected to hold less than a quarter of the scene's groups: the scatter pass's short rounds
+    const bool short_rounds = c->compact_short >= 0 ? c->compact_short != 0
+                                                    : (pl.work && pl.list_estimate && pl.list_estimate * 4ull < pl.s.n_groups);
     HIPCHK(c, mcull::launch_compact(pl.s, (const uint64_t *)o.mask.p, (const uint32_t *)o.tile_counts.p,
                                     pl.two_level ? (uint64_t *)o.tile_offsets.p : nullptr, pl.list, pl.capacity,
-                                    (uint32_t *)o.inst_first.p, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
+                                    (uint32_t *)o.inst_first.p, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream, short_rounds));
     HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, (const uint32_t *)o.inst_first.p, nullptr,
                                           (const uint64_t *)pl.total, nullptr, 0, pl.lay, pl.commands,
                                           (uint32_t *)o.tile_counts.p, c->stream,
@@ -1249,7 +1255,7 @@ int mcull_cull_static(mcull_ctx *c, const mcull_globals *g, const mcull_cull_par
         HIPCHK(c, mcull::launch_zero_words(tile_counts, pl.n_tiles, c->stream));
         HIPCHK(c, mcull::launch_cull_mask(pl.s, pl.v, mask, tile_counts, pl.streaming, c->stream, nullptr));
         HIPCHK(c, mcull::launch_compact(pl.s, mask, tile_counts, pl.two_level ? tile_offsets : nullptr, pl.list, pl.capacity,
-                                        inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream));
+                                        inst_first, pl.total, pl.n_pairs * 8ull > (64ull << 20), c->stream, c->compact_short == 1));
         HIPCHK(c, mcull::launch_emit_commands(pl.s, pl.uniform_count, inst_first, nullptr, (const uint64_t *)pl.total, nullptr, 0,
                                               pl.lay, pl.commands, tile_counts, c->stream, pl.two_level ? tile_offsets : nullptr,
                                               inst_first));

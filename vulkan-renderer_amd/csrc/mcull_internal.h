@@ -148,7 +148,7 @@ hipError_t launch_classify_views(const SceneDev &s, const float4 *spheres, bool 
                                  hipStream_t st);
 hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_t *tile_counts,
                           uint64_t *tile_offsets, mcull_visible *list, uint64_t capacity, uint32_t *inst_first,
-                          uint64_t *total, bool streaming, hipStream_t st);
+                          uint64_t *total, bool streaming, hipStream_t st, bool short_rounds = false);  // short_rounds: a sparse list is expected
 // scatter + commands of n_views (<= MCULL_MAX_VIEWS) views of one scene in three launches; leaves every view's tile counters zero
 hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint32_t n_views, const ViewTail *views, bool streaming,
                                 hipStream_t st);
