@@ -28,13 +28,20 @@ namespace mcull {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kTileGroups = 256;  // groups per compaction tile = 16384 meshlet-instances
-constexpr uint32_t kRoundGroups = 64;   // groups staged in LDS per output round of the scatter pass (32 KiB)
-// ... of the forms that wait for latency, not for bytes: 16 KiB, seven workgroups per CU instead of four.  The tile-walking
-// form (1 M instances of one mesh: 1.72 -> 1.37 ms for the pass; 16 groups: 1.47 ms; the next tile's ballots and offset
-// asked for one tile ahead on top of it: no change), and SHORT, the one-workgroup-per-tile form behind a work list that
-// is expected to hold less than a quarter of the scene's groups (100 M pairs with the occlusion test, 4 % visible:
-// 51 -> 37 us for the pass; a half-visible list loses with it: 90 -> 97 us).
-constexpr uint32_t kShortRoundGroups = 32;
+// Groups staged in LDS per output round of the scatter pass (compact_body).  The pass stages either the eight bytes of
+// an entry (WIDE: 32 KiB per 64 groups, four workgroups per CU) or two bytes per entry, from which the entry is put together
+// when it is stored (8 KiB per 64 groups: the staging no longer limits how many workgroups share a CU, the stores cost a
+// look-up more).  Measured against each other on one GPU, eight bytes / two bytes:
+//   dense list of one view, one workgroup per tile (100 M pairs, half visible)   0.5001 / 0.5019 ms per step  -> WIDE, 64 groups
+//   dense lists of eight views (37 - 77 % visible)                               2.773 / 2.740 ms            -> two bytes, 128 groups
+//     (two bytes with 64 / 128 / 256 groups per round: 2.746 / 2.731 / 2.743 ms)
+//   the forms that wait for latency rather than for bytes - the tile-walking form (scenes that skip empty tiles) and
+//   SHORT, one workgroup per tile behind a work list expected to hold under a quarter of the scene's groups:
+//     1 M instances of one mesh 16.10 / 16.00 ms, 100 M pairs with the occlusion test (4 % visible) 0.199 / 0.196 ms
+//                                                                                 -> two bytes, 64 groups (128: 16.05, 0.197)
+//   (with eight bytes these forms wanted rounds of 32 groups, seven workgroups per CU: 1.72 -> 1.37 ms and 51 -> 37 us for the pass)
+constexpr uint32_t kRoundGroups = 128;       // two-byte staging, dense lists
+constexpr uint32_t kShortRoundGroups = 64;   // every other form
 constexpr uint32_t kScanMinTiles = 1024;  // scenes with more tiles get their tile offsets from scan_tiles_kernel
 constexpr int kScanBlock = 1024;          // threads of that kernel's single workgroup
 constexpr int kScanPerThread = 8;         // consecutive counters per thread and iteration
@@ -1878,21 +1885,27 @@ __global__ __launch_bounds__(kScanBlock) void scan_tiles_views_kernel(ViewTails 
 // workgroups walks the tiles with a stride instead of one workgroup per tile, so that an empty tile costs a scalar load
 // and a branch, not a workgroup (1 M instances of one mesh, 851 000 tiles: 1.5 ms of this pass were workgroups that
 // started and left).
-template <bool NT, bool LOOP, bool SHORT>
+template <bool NT, bool LOOP, bool SHORT, bool WIDE>
 __device__ __forceinline__ void compact_body(
     const uint64_t *__restrict__ mask, const uint32_t *__restrict__ tile_counts,
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
     unsigned long long *__restrict__ total, uint32_t split, uint32_t skip_empty) {
     __shared__ uint64_t s_word[kBlock];
-    __shared__ uint32_t s_off[kBlock], s_inst[kBlock], s_first[kBlock];
+    __shared__ uint32_t s_off[kBlock];
+    __shared__ uint2 s_fi[kBlock];  // {first meshlet, instance} of the tile's groups
     __shared__ uint32_t s_wave[kWaves];
     __shared__ unsigned long long s_sum[kWaves];
-    constexpr uint32_t kRound = (LOOP || SHORT) ? kShortRoundGroups : kRoundGroups;  // groups staged per output round
-    __shared__ unsigned long long s_stage[kRound * 64];
+    constexpr uint32_t kRound = (LOOP || SHORT || WIDE) ? kShortRoundGroups : kRoundGroups;  // groups staged per output round
+    // what is staged per surviving entry is two bytes - its group within the round and its lane; the eight bytes that go
+    // out are put together from the group's record when they are stored
+    // (WIDE: the eight bytes themselves, for the dense list of a single view - see kRoundGroups)
+    __shared__ uint16_t s_code[WIDE ? 1 : kRound * 64];
+    __shared__ unsigned long long s_wide[WIDE ? kRound * 64 : 1];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t round_span = kTileGroups / split;  // groups whose entries this workgroup writes
+    // (kRound <= round_span: the launchers pair more than one workgroup per tile with the short rounds)
     auto do_tile = [&](const uint32_t tile_idx, const uint32_t part_idx) {
     unsigned long long running;
     if (tile_offsets) {
@@ -1942,8 +1955,7 @@ __device__ __forceinline__ void compact_body(
     const uint32_t excl = block_exclusive_scan((uint32_t)__popcll(word), s_wave, &tile_total);
     s_word[threadIdx.x] = word;
     s_off[threadIdx.x] = excl;
-    s_inst[threadIdx.x] = inst;
-    s_first[threadIdx.x] = first;
+    s_fi[threadIdx.x] = make_uint2(first, inst);
     // firstTask of an instance = list offset of its first group (exclusive scan in instance order)
     if (g < g_end && is_first_group && threadIdx.x / round_span == part_idx) inst_first[inst] = (uint32_t)(running + excl);
     __syncthreads();
@@ -1970,7 +1982,8 @@ __device__ __forceinline__ void compact_body(
                 const uint64_t w = s_word[gidx];
                 if ((w >> lane) & 1ull) {
                     const uint32_t li = s_off[gidx] - round_off + (uint32_t)__popcll(w & ((1ull << lane) - 1ull));
-                    s_stage[li] = ((unsigned long long)(s_first[gidx] + lane) << 32) | s_inst[gidx];
+                    if (WIDE) s_wide[li] = ((unsigned long long)(s_fi[gidx].x + lane) << 32) | s_fi[gidx].y;
+                    else s_code[li] = (uint16_t)(((gidx - gbeg) << 6) | lane);
                 }
             }
         }
@@ -1978,22 +1991,28 @@ __device__ __forceinline__ void compact_body(
         const unsigned long long s0 = running + round_off;
         const uint32_t odd = ((uint32_t)s0 + base_lead) & 15u;  // entries between the line boundary and the round's first one
         unsigned long long *out = reinterpret_cast<unsigned long long *>(list);
+        auto entry = [&](int32_t at) {
+            if (WIDE) return s_wide[at];
+            const uint32_t code = s_code[at];
+            const uint2 fi = s_fi[gbeg + (code >> 6)];
+            return ((unsigned long long)(fi.x + (code & 63u)) << 32) | fi.y;
+        };
         for (uint32_t p = threadIdx.x; 2 * p < n_r + odd; p += kBlock) {
             const int32_t li = (int32_t)(2 * p) - (int32_t)odd;
             const bool lo = li >= 0, hi = (uint32_t)(li + 1) < n_r;
             const unsigned long long slot = s0 + (long long)li;
             if (lo && hi && slot + 1 < capacity) {
-                const ull2v e = {s_stage[li], s_stage[li + 1]};
+                const ull2v e = {entry(li), entry(li + 1)};
                 if (NT) __builtin_nontemporal_store(e, reinterpret_cast<ull2v *>(out + slot));
                 else *reinterpret_cast<ull2v *>(out + slot) = e;
             } else {
                 if (lo && slot < capacity) {
-                    if (NT) __builtin_nontemporal_store(s_stage[li], out + slot);
-                    else out[slot] = s_stage[li];
+                    if (NT) __builtin_nontemporal_store(entry(li), out + slot);
+                    else out[slot] = entry(li);
                 }
                 if (hi && slot + 1 < capacity) {
-                    if (NT) __builtin_nontemporal_store(s_stage[li + 1], out + slot + 1);
-                    else out[slot + 1] = s_stage[li + 1];
+                    if (NT) __builtin_nontemporal_store(entry(li + 1), out + slot + 1);
+                    else out[slot + 1] = entry(li + 1);
                 }
             }
         }
@@ -2034,16 +2053,16 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(
     const unsigned long long *__restrict__ tile_offsets, const uint4 *__restrict__ group_rec, uint32_t groups_per_instance,
     uint32_t n_groups, mcull_visible *__restrict__ list, uint64_t capacity, uint32_t *__restrict__ inst_first,
     unsigned long long *__restrict__ total, uint32_t split, uint32_t skip_empty) {
-    compact_body<NT, LOOP, SHORT>(mask, tile_counts, tile_offsets, group_rec, groups_per_instance, n_groups, list, capacity, inst_first, total,
+    compact_body<NT, LOOP, SHORT, !LOOP && !SHORT>(mask, tile_counts, tile_offsets, group_rec, groups_per_instance, n_groups, list, capacity, inst_first, total,
                            split, skip_empty);
 }
 
-template <bool NT, bool LOOP = false>
+template <bool NT, bool LOOP = false, bool SHORT = false>
 __global__ __launch_bounds__(kBlock) void compact_views_kernel(ViewTails tails, uint32_t with_offsets, const uint4 *__restrict__ group_rec,
                                                                uint32_t groups_per_instance, uint32_t n_groups, uint32_t split,
                                                                uint32_t skip_empty) {
     const ViewTail &t = tails.t[blockIdx.y];
-    compact_body<NT, LOOP, false>(t.mask, t.tile_counts, with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_rec,
+    compact_body<NT, LOOP, SHORT, false>(t.mask, t.tile_counts, with_offsets ? (const unsigned long long *)t.tile_offsets : nullptr, group_rec,
                            groups_per_instance, n_groups, t.list, t.capacity, t.inst_first, (unsigned long long *)t.total, split, skip_empty);
 }
 
@@ -2438,6 +2457,8 @@ hipError_t launch_compact(const SceneDev &s, const uint64_t *mask, const uint32_
                                s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first, (unsigned long long *)total, 1u, 1u);
         return hipGetLastError();
     }
+    static_assert(kShortRoundGroups <= kTileGroups / 4 && kRoundGroups <= kTileGroups, "a round never exceeds what one workgroup writes");
+    if (split > 1u) short_rounds = true;  // split <= 4: a workgroup's 64 groups or more hold a short round, not always a long one
     if (short_rounds && streaming)
         hipLaunchKernelGGL((compact_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, mask, tile_counts, offs,
                            s.group_rec, s.groups_per_instance, (uint32_t)s.n_groups, list, capacity, inst_first,
@@ -2473,15 +2494,18 @@ hipError_t launch_ordered_tails(const SceneDev &s, uint32_t uniform_count, uint3
         if (e != hipSuccess) return e;
     }
     const uint32_t gx = skip_empty ? (tiles < 8192u ? tiles : 8192u) : tiles * split;
-#define MCULL_LAUNCH_COMPACT_VIEWS(NT_, LOOP_)                                                                                    \
-    hipLaunchKernelGGL((compact_views_kernel<NT_, LOOP_>), dim3(gx, n_views), dim3(kBlock), 0, st, tails, offsets ? 1u : 0u, s.group_rec, \
+#define MCULL_LAUNCH_COMPACT_VIEWS(NT_, LOOP_, SHORT_)                                                                             \
+    hipLaunchKernelGGL((compact_views_kernel<NT_, LOOP_, SHORT_>), dim3(gx, n_views), dim3(kBlock), 0, st, tails, offsets ? 1u : 0u, s.group_rec, \
                        s.groups_per_instance, (uint32_t)s.n_groups, skip_empty ? 1u : split, skip_empty ? 1u : 0u)
     if (skip_empty) {
-        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, true);
-        else MCULL_LAUNCH_COMPACT_VIEWS(false, true);
+        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, true, false);
+        else MCULL_LAUNCH_COMPACT_VIEWS(false, true, false);
+    } else if (split > 1u) {  // several workgroups per tile: the short rounds (see launch_compact)
+        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, false, true);
+        else MCULL_LAUNCH_COMPACT_VIEWS(false, false, true);
     } else {
-        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, false);
-        else MCULL_LAUNCH_COMPACT_VIEWS(false, false);
+        if (streaming) MCULL_LAUNCH_COMPACT_VIEWS(true, false, false);
+        else MCULL_LAUNCH_COMPACT_VIEWS(false, false, false);
     }
 #undef MCULL_LAUNCH_COMPACT_VIEWS
     hipError_t e = hipGetLastError();
