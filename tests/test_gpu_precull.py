@@ -298,3 +298,35 @@ def test_grid_sized_for_an_estimate_of_the_list(mc, O, H, kitten, monkeypatch, e
             compare(mc, c, ref, n_inst)
             marked, tested, per_group = c.precull_stats()
             assert per_group and 0 < marked < tested
+
+
+def test_alternating_test_sets_keep_their_own_list_estimates(mc, O, H, monkeypatch):
+    """The two phases of a frame alternate on one context: frustum + cone (a long work list), then all three tests (a short
+    one).  Each set of tests has its own estimate of the list's length, takes its turn at the probe that measures it, and
+    the estimate-sized mask pass, its walking second launch and the scatter pass's form for sparse lists give the oracle's
+    outputs frame after frame."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_FORCE_STREAMING", "1")  # the kernels that size their grid for the estimate
+    with mc.Context(0) as c:
+        monkeypatch.delenv("MCULL_PRECULL_MIN_GROUPS")
+        monkeypatch.delenv("MCULL_FORCE_STREAMING")
+        n_inst, per = 3000, 256
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=31)
+        t = H.synthetic_transforms(n_inst, extent=60.0, seed=32)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        w, h = 640, 360
+        depth = H.synthetic_depth(w, h, n_discs=30, seed=33)
+        depth[:, : w // 2] = 0.9  # a wall over half the image: most of what the planes keep is hidden
+        g = H.create_globals(eye=(70.0, 60.0, 50.0), width=w, height=h)
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        c.set_instance_ranges(off, cnt)
+        c.hiz_build(depth, view=0)
+        view = O.View(g, O.hiz_build(depth), w, h)
+        refs = {k: O.cull_scene(view, t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=k) for k in (3, 7, 1)}
+        assert refs[7].total * 3 < refs[3].total, "the scene should separate the two lists"
+        for frame in range(8):
+            for k in (3, 7) if frame != 5 else (1, 7, 3):  # a third set of tests turns up once
+                c.cull(g, tests=k, hiz_view=0, write_mask=True)
+                compare(mc, c, refs[k], n_inst)

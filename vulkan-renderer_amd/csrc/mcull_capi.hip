@@ -191,7 +191,13 @@ struct mcull_ctx {
         // mask pass sizes its grid for it (launch_cull_mask)
         bool probe_in_groups = false, probe_group_level = false;
         uint32_t probe_groups_per_instance = 0;
-        uint64_t list_estimate = 0;
+        // one estimate per set of tests: the two phases of a frame (frustum + cone, then all three) alternate on one slot, and
+        // the short list of the second must not size the grid of the first (100 M pairs: 0.798 instead of 0.703 ms per pair of
+        // culls while they shared one)
+        uint64_t list_estimate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t probe_tests = 0;          // the tests of the cull that owns, or last owned, the probe
+        bool other_tests_waiting = false;  // a cull with other tests passed by while that probe was pending: its turn next
+        uint32_t probe_deferred = 0;       // times in a row the last owner has left the probe to the others
     } out[MCULL_MAX_VIEWS];
     uint32_t cur = 0;
 };
@@ -247,7 +253,9 @@ void invalidate_results(mcull_ctx *c) {
         o.last.valid = false;
         // what the pre-cull learnt about the old scene says nothing about the new one
         o.probe_pending = false;
-        o.list_estimate = 0;
+        for (auto &e : o.list_estimate) e = 0;
+        o.other_tests_waiting = false;
+        o.probe_deferred = 0;
         o.precull_cooldown = o.group_cooldown = 0;
     }
     c->views_probe_pending = false;
@@ -986,7 +994,8 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 if (kept != 0xffffffffu) {  // the cull that ran it has finished
                     o.probe_pending = false;
                     if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown = kPrecullCooldown;
-                    o.list_estimate = o.probe_group_level ? 0 : o.probe_in_groups ? (uint64_t)kept : (uint64_t)kept * o.probe_groups_per_instance;
+                    o.list_estimate[o.probe_tests & 7u] =
+                        o.probe_group_level ? 0 : o.probe_in_groups ? (uint64_t)kept : (uint64_t)kept * o.probe_groups_per_instance;
                     // the group level: what it kept (the mask pass's list) against what it was handed (kept_host[2])
                     const uint32_t handed = c->kept_host[2];
                     if (o.probe_group_level && handed != 0xffffffffu && (uint64_t)kept * 10 > (uint64_t)handed * 9)
@@ -1052,7 +1061,20 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 plan->v.win_levels = win_levels;
             }
             }
-            if (c->precull_adaptive && !o.probe_pending) {
+            // One probe in flight per slot.  Culls with different tests take turns at it: the one that owned the last probe
+            // leaves the next to a cull with other tests that has passed by meanwhile (at most four times in a row, should
+            // those not come back).
+            const uint32_t my_tests = p.tests & 7u;
+            if (o.probe_pending && my_tests != o.probe_tests) o.other_tests_waiting = true;
+            bool my_turn = true;
+            if (!o.probe_pending && my_tests == o.probe_tests && o.other_tests_waiting && o.probe_deferred < 4u) {
+                o.probe_deferred++;
+                my_turn = false;
+            }
+            if (c->precull_adaptive && !o.probe_pending && my_turn) {
+                o.probe_tests = my_tests;
+                o.other_tests_waiting = false;
+                o.probe_deferred = 0;
                 c->kept_host[(size_t)(&o - c->out)] = 0xffffffffu;  // until this cull's mask pass reports
                 if (plan->group_work) c->kept_host[2] = 0xffffffffu;       // and its group level (single-view culls are slot 0)
                 o.probe_pending = true;
@@ -1065,9 +1087,10 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             // the walking form that takes what lies beyond the estimate reads two flag bits off the top of an entry
             if (!plan->hand_on && (ranged || c->n_instances < (1ull << 30))) {
                 // 3 % and 1 024 groups of margin on what was reported; not worth a second launch unless it spares 4 096 groups' workgroups
-                const uint64_t padded = o.list_estimate + o.list_estimate / 32 + 1024;
+                const uint64_t known = o.list_estimate[p.tests & 7u];
+                const uint64_t padded = known + known / 32 + 1024;
                 plan->list_estimate = c->precull_estimate >= 0 ? (uint64_t)c->precull_estimate
-                                      : (c->precull_adaptive && o.list_estimate && padded + 4096 < s.n_groups) ? padded : 0;
+                                      : (c->precull_adaptive && known && padded + 4096 < s.n_groups) ? padded : 0;
             }
         }
         if (!o.tile_counts.p || o.tile_counts.cap < (size_t)plan->n_tiles * 4) o.counters_clean = false;
