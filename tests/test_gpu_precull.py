@@ -330,3 +330,37 @@ def test_alternating_test_sets_keep_their_own_list_estimates(mc, O, H, monkeypat
             for k in (3, 7) if frame != 5 else (1, 7, 3):  # a third set of tests turns up once
                 c.cull(g, tests=k, hiz_view=0, write_mask=True)
                 compare(mc, c, refs[k], n_inst)
+
+
+def test_the_back_off_of_one_test_set_leaves_the_other_alone(mc, O, H, kitten, monkeypatch, forced):
+    """Every instance in view and hidden behind a wall: the planes remove nothing, so the frustum + cone culls drop the
+    instance level for a while - the culls with the occlusion test, which alternate with them on the same context and
+    whose instance level removes nearly everything, keep it."""
+    if not forced.adaptive:
+        pytest.skip("the run's switches take the back-off away")
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    ml = kitten["meshlets"]
+    n = 64
+    w, h = 320, 240
+    t = H.synthetic_transforms(n, extent=1.0, seed=2)
+    g = H.create_globals(eye=(6.0, 6.0, 6.0), width=w, height=h, meshlet_count=len(ml))
+    depth = np.full((h, w), 0.9, dtype="<f4")  # reverse-Z: nearer than everything
+    view = O.View(g, O.hiz_build(depth), w, h)
+    ref3 = O.cull_scene(O.View(g), t, ml, tests=3)
+    ref7 = O.cull_scene(view, t, ml, tests=7)
+    assert ref7.total == 0 < ref3.total
+    with mc.Context(0) as c:
+        c.upload_meshlets(ml)
+        c.upload_transforms(t)
+        c.hiz_build(depth, view=0)
+        ran3, ran7 = [], []
+        for frame in range(20):
+            c.cull(g, tests=3, write_mask=True)
+            compare(mc, c, ref3, n)
+            ran3.append(c.precull_stats()[1] > 0)
+            c.cull(g, tests=7, hiz_view=0, write_mask=True)
+            compare(mc, c, ref7, n)
+            marked, tested, _ = c.precull_stats()
+            ran7.append(tested > 0 and marked == tested)
+        assert ran3[0] and not any(ran3[2:12]), ran3   # backed off (the probe's answer may take a frame to be looked at)
+        assert all(ran7), ran7

@@ -185,8 +185,10 @@ struct mcull_ctx {
         bool counts_slow_pairs = false; // the last cull counted the pairs that left the fast predicate forms
         bool probe_pending = false;     // a pre-cull ran and its kept count has not been looked at yet
         uint64_t probe_units = 0;
-        uint32_t precull_cooldown = 0;  // culls still to go without the pre-cull
-        uint32_t group_cooldown = 0;    // culls still to go without the group level (it removed less than a tenth of what it was handed)
+        // per set of tests (index tests & 7), like the list estimates below: that the planes alone remove nothing says nothing
+        // about a cull of the same scene with the occlusion test
+        uint32_t precull_cooldown[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // culls still to go without the pre-cull
+        uint32_t group_cooldown[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // culls still to go without the group level (it removed less than a tenth of what it was handed)
         // what the work list of the slot's last finished pre-culled cull held, in groups (0 = unknown): the streaming
         // mask pass sizes its grid for it (launch_cull_mask)
         bool probe_in_groups = false, probe_group_level = false;
@@ -256,7 +258,7 @@ void invalidate_results(mcull_ctx *c) {
         for (auto &e : o.list_estimate) e = 0;
         o.other_tests_waiting = false;
         o.probe_deferred = 0;
-        o.precull_cooldown = o.group_cooldown = 0;
+        for (int k = 0; k < 8; k++) o.precull_cooldown[k] = o.group_cooldown[k] = 0;
     }
     c->views_probe_pending = false;
     c->views_cooldown = 0;
@@ -993,17 +995,17 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 const uint32_t kept = c->kept_host[slot];
                 if (kept != 0xffffffffu) {  // the cull that ran it has finished
                     o.probe_pending = false;
-                    if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown = kPrecullCooldown;
+                    if ((uint64_t)kept * 10 > o.probe_units * 9) o.precull_cooldown[o.probe_tests & 7u] = kPrecullCooldown;
                     o.list_estimate[o.probe_tests & 7u] =
                         o.probe_group_level ? 0 : o.probe_in_groups ? (uint64_t)kept : (uint64_t)kept * o.probe_groups_per_instance;
                     // the group level: what it kept (the mask pass's list) against what it was handed (kept_host[2])
                     const uint32_t handed = c->kept_host[2];
                     if (o.probe_group_level && handed != 0xffffffffu && (uint64_t)kept * 10 > (uint64_t)handed * 9)
-                        o.group_cooldown = kPrecullCooldown;
+                        o.group_cooldown[o.probe_tests & 7u] = kPrecullCooldown;
                 }
             }
-            if (o.precull_cooldown) {
-                o.precull_cooldown--;
+            if (o.precull_cooldown[p.tests & 7u]) {
+                o.precull_cooldown[p.tests & 7u]--;
                 precull = false;
             }
         }
@@ -1029,8 +1031,8 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             plan->hand_on = c->precull_flags && c->n_instances < (1ull << 30) && !plan->streaming;
             // instances of 32 groups and more: a group level thins the list once more
             const bool group_level = plan->hand_on && c->precull_groups && s.n_groups >= 32ull * c->n_instances && s.n_groups < (1ull << 30);
-            if (group_level && c->precull_adaptive && o.group_cooldown) {
-                o.group_cooldown--;
+            if (group_level && c->precull_adaptive && o.group_cooldown[p.tests & 7u]) {
+                o.group_cooldown[p.tests & 7u]--;
             } else if (group_level) {
                 if (!c->gspheres_valid) {
                     if ((rc = ensure(c, c->group_spheres, mcull::range_sphere_bytes((uint32_t)c->n_meshlets)))) return rc;
