@@ -364,3 +364,45 @@ def test_the_back_off_of_one_test_set_leaves_the_other_alone(mc, O, H, kitten, m
             ran7.append(tested > 0 and marked == tested)
         assert ran3[0] and not any(ran3[2:12]), ran3   # backed off (the probe's answer may take a frame to be looked at)
         assert all(ran7), ran7
+
+
+def test_new_matrices_for_the_same_instances_keep_the_hints_and_the_results_right(mc, O, H, monkeypatch):
+    """An animated scene uploads new matrices for the same instances every frame: what the last frame's pre-cull reported
+    stays the guess for the next one (a different instance count starts from scratch).  Frames that drift, a frame in which
+    nearly everything leaves the view and the frame after it, in which everything is back - the estimate far too long, then
+    far too short: the oracle's outputs every time."""
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_FORCE_STREAMING", "1")
+    with mc.Context(0) as c:
+        monkeypatch.delenv("MCULL_PRECULL_MIN_GROUPS")
+        monkeypatch.delenv("MCULL_FORCE_STREAMING")
+        n_inst, per = 2500, 256
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=41)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        g = H.create_globals(eye=(70.0, 60.0, 50.0), width=640, height=360)
+        view = O.View(g)
+        c.upload_bounds_soa(cone, sphere)
+        base = H.synthetic_transforms(n_inst, extent=60.0, seed=42)
+        c.upload_transforms(base)
+        c.set_instance_ranges(off, cnt)
+        totals = []
+        for frame in range(10):
+            t = base.copy()
+            m = t["model"].reshape(n_inst, 4, 4).copy()
+            m[:, 3, :3] += np.float32(0.5 * frame)               # drift
+            if frame == 6:
+                m[: n_inst - 20, 3, :3] += np.float32(5000.0)    # nearly everything far outside the planes
+            t["model"] = m.reshape(n_inst, 16)
+            c.upload_transforms(t)
+            ref = O.cull_scene(view, t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=3)
+            for _ in range(2):
+                c.cull(g, tests=3, write_mask=True)
+                compare(mc, c, ref, n_inst)
+            totals.append(ref.total)
+        assert totals[6] * 20 < totals[5] and totals[7] > totals[6] * 20
+        c.upload_transforms(base[: n_inst // 2])                 # another count: from scratch
+        c.set_instance_ranges(off[: n_inst // 2], cnt[: n_inst // 2])
+        ref = O.cull_scene(view, base[: n_inst // 2], cone_axis_w=cone, centre_radius=sphere, ranges=(off[: n_inst // 2], cnt[: n_inst // 2]), tests=3)
+        c.cull(g, tests=3, write_mask=True)
+        compare(mc, c, ref, n_inst // 2)

@@ -250,9 +250,13 @@ void release(DevBuf &b) {
 }
 
 // a changed scene makes every stored cull result meaningless
-void invalidate_results(mcull_ctx *c) {
+// keep_hints: the scene has the same shape as before (new matrices for the same instances - an animated frame): what the
+// pre-cull learnt about the last frame is still the best guess for this one, and no result depends on it
+void invalidate_results(mcull_ctx *c, bool keep_hints = false) {
+    for (auto &o : c->out) o.last.valid = false;
+    c->cur = 0;
+    if (keep_hints) return;
     for (auto &o : c->out) {
-        o.last.valid = false;
         // what the pre-cull learnt about the old scene says nothing about the new one
         o.probe_pending = false;
         for (auto &e : o.list_estimate) e = 0;
@@ -606,8 +610,9 @@ int mcull_upload_transforms(mcull_ctx *c, const mcull_transform *transforms, uin
     if ((rc = copy_in(c, c->transforms.p, transforms, count * sizeof(mcull_transform), mem))) return rc;
     HIPCHK(c, mcull::launch_xform_scale((const float4 *)c->transforms.p, (uint32_t)count, (float *)c->xf_scale.p,
                                         c->stream));
+    const bool same_shape = count == c->n_instances;
     c->n_instances = count;
-    invalidate_results(c);
+    invalidate_results(c, same_shape);
     return MCULL_OK;
 }
 
