@@ -406,3 +406,53 @@ def test_new_matrices_for_the_same_instances_keep_the_hints_and_the_results_righ
         ref = O.cull_scene(view, base[: n_inst // 2], cone_axis_w=cone, centre_radius=sphere, ranges=(off[: n_inst // 2], cnt[: n_inst // 2]), tests=3)
         c.cull(g, tests=3, write_mask=True)
         compare(mc, c, ref, n_inst // 2)
+
+
+def test_a_captured_cull_ignores_the_back_off_and_survives_a_wrong_estimate(mc, O, H, monkeypatch, forced):
+    """A cull captured into a graph is replayed for cameras the capturing call never saw.  Captured while the instance
+    level is in its back-off (the camera of the capture sees everything) and with the list estimate of a camera that sees
+    almost nothing, the replays still run the instance level and give the oracle's outputs for a camera that sees
+    everything, one that sees nothing and one in between."""
+    import torch
+
+    monkeypatch.setenv("MCULL_PRECULL_MIN_GROUPS", "1")
+    monkeypatch.setenv("MCULL_FORCE_STREAMING", "1")
+    stream = torch.cuda.Stream()
+    with mc.Context(0, stream=stream.cuda_stream) as c, torch.cuda.stream(stream):
+        monkeypatch.delenv("MCULL_PRECULL_MIN_GROUPS")
+        monkeypatch.delenv("MCULL_FORCE_STREAMING")
+        n_inst, per = 2500, 256
+        cone, sphere = H.synthetic_bounds(n_inst * per, seed=51)
+        t = H.synthetic_transforms(n_inst, extent=20.0, seed=52)
+        off = (np.arange(n_inst, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_inst, per, dtype="<u4")
+        cams = {"all": H.create_globals(eye=(150.0, 140.0, 120.0), width=640, height=360),
+                "none": H.create_globals(eye=(150.0, 140.0, 120.0), centre=(300.0, 280.0, 240.0), width=640, height=360),
+                "some": H.create_globals(eye=(30.0, 5.0, 8.0), width=640, height=360)}
+        refs = {k: O.cull_scene(O.View(g), t, cone_axis_w=cone, centre_radius=sphere, ranges=(off, cnt), tests=3) for k, g in cams.items()}
+        assert refs["none"].total == 0 < refs["some"].total < refs["all"].total
+        c.upload_bounds_soa(cone, sphere)
+        c.upload_transforms(t)
+        c.set_instance_ranges(off, cnt)
+        g_dev = {k: torch.from_numpy(np.ascontiguousarray(g, dtype=mc.GLOBALS).reshape(1).view("u1").reshape(-1).copy()).to("cuda:0")
+                 for k, g in cams.items()}
+        live = torch.empty_like(g_dev["all"])
+        torch.cuda.synchronize()
+        for k in ("none", "none", "none", "all", "all"):  # the estimate of "none", then the back-off that "all" earns
+            live.copy_(g_dev[k])
+            c.cull_device_globals(live.data_ptr(), per, tests=3, write_mask=True)
+            compare(mc, c, refs[k], n_inst)
+        if forced.adaptive:
+            c.cull_device_globals(live.data_ptr(), per, tests=3, write_mask=True)
+            c.synchronize()
+            assert c.precull_stats()[1] == 0, "the capture below should fall into the back-off"
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            c.cull_device_globals(live.data_ptr(), per, tests=3, write_mask=True)
+        for k in ("all", "none", "some", "all"):
+            live.copy_(g_dev[k])
+            graph.replay()
+            stream.synchronize()
+            compare(mc, c, refs[k], n_inst)
+            marked, tested, _ = c.precull_stats()
+            assert tested > 0 and (k != "none" or marked == tested), (k, marked, tested)

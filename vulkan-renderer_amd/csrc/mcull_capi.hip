@@ -994,7 +994,15 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
     } else {
         bool precull = !multi_view && (p.tests & (MCULL_TEST_FRUSTUM | MCULL_TEST_HIZ)) && !(p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) &&
                        s.n_groups >= c->precull_min_groups;
-        if (precull && c->precull_adaptive) {
+        // A cull that is being captured into a graph will be replayed for cameras and scenes this call knows nothing about:
+        // it runs both levels whatever the back-off says, owns no probe, and sizes its grid with a wide margin.
+        bool capturing = false;
+        {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess) capturing = cs != hipStreamCaptureStatusNone;
+        }
+        const bool adaptive = c->precull_adaptive && !capturing;
+        if (precull && adaptive) {
             const size_t slot = (size_t)(&o - c->out);
             if (o.probe_pending) {
                 const uint32_t kept = c->kept_host[slot];
@@ -1036,7 +1044,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             plan->hand_on = c->precull_flags && c->n_instances < (1ull << 30) && !plan->streaming;
             // instances of 32 groups and more: a group level thins the list once more
             const bool group_level = plan->hand_on && c->precull_groups && s.n_groups >= 32ull * c->n_instances && s.n_groups < (1ull << 30);
-            if (group_level && c->precull_adaptive && o.group_cooldown[p.tests & 7u]) {
+            if (group_level && adaptive && o.group_cooldown[p.tests & 7u]) {
                 o.group_cooldown[p.tests & 7u]--;
             } else if (group_level) {
                 if (!c->gspheres_valid) {
@@ -1078,7 +1086,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
                 o.probe_deferred++;
                 my_turn = false;
             }
-            if (c->precull_adaptive && !o.probe_pending && my_turn) {
+            if (adaptive && !o.probe_pending && my_turn) {
                 o.probe_tests = my_tests;
                 o.other_tests_waiting = false;
                 o.probe_deferred = 0;
@@ -1095,7 +1103,7 @@ int plan_cull(mcull_ctx *c, const mcull_globals *g, uint32_t meshlet_count, cons
             if (!plan->hand_on && (ranged || c->n_instances < (1ull << 30))) {
                 // 3 % and 1 024 groups of margin on what was reported; not worth a second launch unless it spares 4 096 groups' workgroups
                 const uint64_t known = o.list_estimate[p.tests & 7u];
-                const uint64_t padded = known + known / 32 + 1024;
+                const uint64_t padded = capturing ? known + known / 2 + 4096 : known + known / 32 + 1024;
                 plan->list_estimate = c->precull_estimate >= 0 ? (uint64_t)c->precull_estimate
                                       : (c->precull_adaptive && known && padded + 4096 < s.n_groups) ? padded : 0;
             }
@@ -1368,7 +1376,11 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
             if (pl[i].p.flags & MCULL_CULL_NO_INSTANCE_PRECULL) classify = false;
         }
         classify = classify && any_test;
-        if (classify && c->precull_adaptive) {
+        // (a captured call is replayed for cameras this call knows nothing about: no back-off, no probe - see plan_cull)
+        hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+        const bool views_adaptive = c->precull_adaptive &&
+                                    !(hipStreamIsCapturing(c->stream, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone);
+        if (classify && views_adaptive) {
             if (c->views_probe_pending) {
                 const uint32_t useful = c->kept_host[1];
                 if (useful != 0xffffffffu) {
@@ -1389,7 +1401,7 @@ int views_impl(mcull_ctx *c, uint32_t n_views, const mcull_globals *globals, con
             HIPCHK(c, mcull::launch_zero_words(useful_dev, 1, c->stream));
             HIPCHK(c, mcull::launch_classify_views(pl[0].s, (const float4 *)c->range_spheres.p, c->have_ranges, n_views, vc, view_dev,
                                                    (uint8_t *)c->view_flags.p, useful_dev, c->stream));
-            if (c->precull_adaptive && !c->views_probe_pending) {
+            if (views_adaptive && !c->views_probe_pending) {
                 c->kept_host[1] = 0xffffffffu;  // until this cull's mask pass reports
                 c->views_probe_pending = true;
                 c->views_probe_units = c->n_instances * n_views;
