@@ -437,3 +437,75 @@ def test_random_pyramids_of_several_views(mc, O, seed):
                     assert a.view("<u4").tobytes() == b.view("<u4").tobytes(), "seed %d %dx%d slot %d level %d" % (seed, w, h, slot, lvl)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
+def test_random_call_sequences(mc, O, H, seed):
+    """The adaptive parts of a context - list-length estimates and back-off per set of tests, the probe taken in turns,
+    window tables made when a pyramid is culled against twice, hints kept across new matrices - see a random sequence of
+    what a renderer does between culls: other tests, another camera, a rebuilt pyramid, moved instances, a changed
+    instance count.  Every cull against the oracle (the back-off left on: these contexts are the library's defaults but
+    for the scene size from which the instance level runs)."""
+    rs = np.random.RandomState(7700 + seed)
+    env = dict(MCULL_PRECULL_MIN_GROUPS="1")
+    if rs.rand() < 0.5:
+        env["MCULL_FORCE_STREAMING"] = "1"
+    c = _context_with(mc, **env)
+    try:
+        per = int(rs.choice([128, 256, 2304]))                       # 2304: 36 groups per instance, the group level's scenes
+        n_all = int(rs.choice([300, 1500])) if per < 2304 else int(rs.choice([40, 150]))
+        cone, sphere = H.synthetic_bounds(n_all * per, seed=seed + 3)
+        base = H.synthetic_transforms(n_all, extent=float(rs.uniform(10.0, 50.0)), seed=seed + 4)
+        w, h = [(320, 200), (640, 360), (501, 333)][rs.randint(3)]
+        cams = [H.create_globals(eye=tuple(rs.uniform(20.0, 90.0, 3)), width=w, height=h, flip_y=bool(rs.rand() < 0.5)),
+                H.create_globals(eye=tuple(rs.uniform(1.0, 8.0, 3)), width=w, height=h),
+                H.create_globals(eye=(60.0, 55.0, 40.0), centre=(120.0, 110.0, 80.0), width=w, height=h)]  # looking away
+        depths = [H.synthetic_depth(w, h, n_discs=int(rs.randint(1, 40)), seed=seed + k) for k in range(2)]
+        depths.append(np.full((h, w), 0.9, dtype="<f4"))             # a wall
+        pyrs = [O.hiz_build(d) for d in depths]
+        c.upload_bounds_soa(cone, sphere)
+        n_inst, t, cur_depth = n_all, base, 0
+        off = (np.arange(n_all, dtype=np.uint64) * per).astype("<u4")
+        cnt = np.full(n_all, per, dtype="<u4")
+
+        def scene():
+            c.upload_transforms(t)
+            c.set_instance_ranges(off[:n_inst], cnt[:n_inst])
+
+        scene()
+        c.hiz_build(depths[0], view=0)
+        refs = {}
+        version = 0
+        for step in range(30):
+            op = rs.rand()
+            if op < 0.12:                                            # the instances move: same count, new matrices
+                t = t.copy()
+                m = t["model"].reshape(n_inst, 4, 4).copy()
+                m[:, 3, :3] += rs.normal(0.0, 2.0, (n_inst, 3)).astype("<f4")
+                t["model"] = m.reshape(n_inst, 16)
+                c.upload_transforms(t)
+                version += 1
+            elif op < 0.17:                                          # another instance count
+                n_inst = int(rs.choice([n_all, n_all // 2, max(1, n_all // 7)]))
+                t = base[:n_inst].copy()
+                scene()
+                version += 1
+            elif op < 0.30:                                          # the pyramid is rebuilt
+                cur_depth = int(rs.randint(len(depths)))
+                c.hiz_build(depths[cur_depth], view=0)
+            tests = int(rs.choice([7, 7, 3, 3, 1, 5, 6, 2]))
+            cam = int(rs.randint(len(cams)))
+            key = (version, cam, tests, cur_depth if tests & 4 else -1)
+            if key not in refs:
+                refs[key] = O.cull_scene(O.View(cams[cam], pyrs[cur_depth], w, h), t, cone_axis_w=cone, centre_radius=sphere,
+                                         ranges=(off[:n_inst], cnt[:n_inst]), tests=tests)
+            ref = refs[key]
+            c.cull(cams[cam], tests=tests, hiz_view=0, write_mask=True)
+            if rs.rand() < 0.6:                                      # not every frame is looked at: the probe's answer may be late
+                assert c.download_count() == ref.total, (step, key)
+                assert np.array_equal(c.download_mask(), ref.mask), (step, key)
+                assert c.download_list().tobytes() == ref.list.tobytes(), (step, key)
+                cmds = c.download_commands(n_inst).view(mc.CMD).reshape(-1)
+                assert np.array_equal(cmds["taskCount"], ref.commands["taskCount"]) and np.array_equal(cmds["firstTask"], ref.commands["firstTask"])
+    finally:
+        c.close()
