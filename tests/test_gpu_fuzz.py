@@ -493,6 +493,19 @@ def test_random_call_sequences(mc, O, H, seed):
             elif op < 0.30:                                          # the pyramid is rebuilt
                 cur_depth = int(rs.randint(len(depths)))
                 c.hiz_build(depths[cur_depth], view=0)
+            if rs.rand() < 0.15:                                     # several views in one pass, all against pyramid 0
+                nv = int(rs.randint(2, 5))
+                vc = [int(rs.randint(len(cams))) for _ in range(nv)]
+                vt = [int(rs.choice([7, 3, 1, 5])) for _ in range(nv)]
+                c.cull_views([cams[k] for k in vc], [dict(tests=k, hiz_view=0, write_mask=True) for k in vt])
+                for v in range(nv):
+                    key = (version, vc[v], vt[v], cur_depth if vt[v] & 4 else -1)
+                    if key not in refs:
+                        refs[key] = O.cull_scene(O.View(cams[vc[v]], pyrs[cur_depth], w, h), t, cone_axis_w=cone, centre_radius=sphere,
+                                                 ranges=(off[:n_inst], cnt[:n_inst]), tests=vt[v])
+                    c.select_result(v)
+                    _compare(mc, c, refs[key], n_inst, (step, "view", v, key))
+                c.select_result(0)
             tests = int(rs.choice([7, 7, 3, 3, 1, 5, 6, 2]))
             cam = int(rs.randint(len(cams)))
             key = (version, cam, tests, cur_depth if tests & 4 else -1)
