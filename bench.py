@@ -613,6 +613,23 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
         moving_ms = el_m / n_m * 1e3
         cameras = None
         views[0] = g
+    two_phase_ms = None
+    if workload == "config4" and args.hiz and not multi and not args.instances and not args.meshlets_per_instance and args.tests is None:
+        # the two phases of a frame taking turns on this context: frustum + cone, then all three tests (each keeps its own
+        # list-length estimate and back-off; a short leg beside the figure of the all-tests cull alone)
+        all_tests = tests
+
+        def pair(k):
+            nonlocal tests
+            tests = all_tests & 3
+            step(2 * k)
+            tests = all_tests
+            step(2 * k + 1)
+
+        n_p = min(steps, 50)
+        el_p, _ = env.timed(pair, steps=n_p, warmup=4)
+        two_phase_ms = el_p / n_p * 1e3
+        tests = all_tests
     # separate, untimed steps for the per-call device time (the event read-back synchronises)
     ctx.enable_timing(True)
     for k in range(min(steps, 10)):
@@ -674,7 +691,7 @@ def cull_leg(env, workload, scaling, steps=None, warmup=None, gather_lists=False
                 tests=tests, views=views, depth=depth, hiz_size=hiz_size, vis_views=vis_views, hiz_pairs=hiz_pairs,
                 precull=dict(marked=pre_marked, tested=pre_tested, unit="groups" if pre_per_group else "instances",
                              **({"group_level": {"dropped": grp_dropped, "tested": grp_tested}} if grp_tested else {})),
-                value=job_pairs * n_views / (elapsed / steps) / 1e9, gather_mode=env.gather_mode, moving_ms=moving_ms,
+                value=job_pairs * n_views / (elapsed / steps) / 1e9, gather_mode=env.gather_mode, moving_ms=moving_ms, two_phase_ms=two_phase_ms,
                 scene=(cone, sphere, xf, off, cnt))
 
 
@@ -741,6 +758,8 @@ def run_cull(env, workload):
                                        ["ordered", "wave-atomic", "block-atomic"][args.compaction]))
         out = base_line(env, "meshlet-instances culled+compacted/sec", "G/s", r["value"], r["elapsed"], r["steps"], name, extra_cfg)
         out["scaling"] = r["scaling"]
+        if r["two_phase_ms"] is not None:
+            out["two_phase_ms_per_pair"] = round(r["two_phase_ms"], 4)  # a frustum + cone cull and an all-tests cull, alternating
         if r["moving_ms"] is not None:
             out["moving_camera_ms_per_step"] = round(r["moving_ms"], 4)  # 0.2 degrees of orbit per step: every cull's list differs from the last one's
         traffic, traffic_src = pmc_traffic(args, workload, n_inst, per)
